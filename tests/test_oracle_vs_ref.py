@@ -1,0 +1,117 @@
+"""The CPU oracle against the LIVE compiled reference (oracle/_ref).
+
+oracle/_ref is built from /root/reference by oracle/Makefile (unmodified sources + tap harness).
+Here (build container) it is built on demand; on the GPU box the prebuilt files travel with the
+tree.  Where neither exists the module skips -- test_oracle_golden.py still pins the oracle
+against the committed reference outputs.
+"""
+import numpy as np
+import pytest
+
+from jpeg_amd.synth import synth_image
+
+
+def _same_coefs(a, b):
+    return len(a.comps) == len(b.comps) and all(
+        (x["id"], x["H"], x["V"], x["bx"], x["by"]) == (y["id"], y["H"], y["V"], y["bx"], y["by"])
+        and np.array_equal(x["coef"], y["coef"]) for x, y in zip(a.comps, b.comps))
+
+
+def test_lut_is_the_reference_lut(oracle, reference):
+    assert np.array_equal(oracle.lut().view(np.uint32), reference.lut().view(np.uint32))
+
+
+def test_block_primitives_random(oracle, reference):
+    rng = np.random.default_rng(3)
+    for t in range(200):
+        scale = 10.0 ** rng.integers(0, 5)
+        blk = (rng.standard_normal(64) * scale).astype(np.float32)
+        assert np.array_equal(oracle.fdct(blk).view(np.uint32), reference.fdct(blk).view(np.uint32))
+        assert np.array_equal(oracle.idct(blk).view(np.uint32), reference.idct(blk).view(np.uint32))
+        Q = rng.integers(1, 256, 64).astype(np.uint16)
+        # include exact .5 ties
+        if t % 4 == 0:
+            blk = (rng.integers(-400, 400, 64) * Q / 2).astype(np.float32)
+        assert np.array_equal(oracle.quantize(blk, Q), reference.quantize(blk, Q))
+
+
+CASES = [
+    # X, Y, nc, P, H, V, q, opt, safe
+    (64, 64, 3, 8, 1, 1, 90, 1, False),
+    (67, 35, 3, 8, 2, 2, 60, 1, False),
+    (130, 18, 3, 8, 2, 1, 85, 0, False),
+    (24, 90, 3, 8, 1, 2, 40, 1, False),
+    (57, 43, 1, 8, 1, 1, 99, 1, False),
+    (160, 96, 1, 12, 1, 1, 75, 1, True),
+    (96, 64, 3, 12, 2, 2, 75, 1, True),
+    (320, 200, 3, 8, 2, 2, 95, 0, False),
+    (16, 16, 3, 8, 2, 2, 5, 1, False),
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_encode_decode_bit_exact(oracle, reference, case):
+    X, Y, nc, P, H, V, q, opt, safe = case
+    img = synth_image(X, Y, nc, P, seed=X * 7 + Y, range_safe=safe)
+    e1, j1, i1 = oracle.encode(img, P=P, H=H, V=V, q=q, optimize=opt)
+    assert e1 == 0
+    e2, j2, i2 = reference.encode(img, P=P, H=H, V=V, q=q, optimize=opt)
+    assert e2 == 0
+    assert _same_coefs(i1, i2)                       # quantised coefficients
+    assert np.array_equal(i1.qtables[:2], i2.qtables[:2])
+    assert j1 == j2                                  # whole codestream incl. DHT of the K.2 optimiser
+    e1, s1, d1 = oracle.decode(j2)
+    e2, s2, d2 = reference.decode(j2)
+    assert e1 == 0 and e2 == 0
+    assert _same_coefs(d1, d2) and _same_coefs(d1, i2)
+    assert np.array_equal(s1, s2)                    # output samples
+    # float frame before rounding, visible region (padding is uninitialised in the reference)
+    assert np.array_equal(d1.frame[:Y, :X].view(np.uint32), d2.frame[:Y, :X].view(np.uint32))
+
+
+def test_random_noise_images(oracle, reference):
+    """High-entropy content: long codes, ZRL runs, big categories."""
+    rng = np.random.default_rng(11)
+    for (X, Y, nc, H, V, q) in [(48, 48, 3, 2, 2, 90), (40, 24, 3, 1, 1, 100), (64, 32, 1, 1, 1, 97)]:
+        img = rng.integers(96, 160, (Y, X, nc) if nc > 1 else (Y, X)).astype(np.uint8)
+        e1, j1, i1 = oracle.encode(img, P=8, H=H, V=V, q=q, optimize=1)
+        e2, j2, i2 = reference.encode(img, P=8, H=H, V=V, q=q, optimize=1)
+        assert e1 == 0 and e2 == 0 and j1 == j2
+        e1, s1, _ = oracle.decode(j1)
+        e2, s2, _ = reference.decode(j1)
+        assert e1 == 0 and e2 == 0 and np.array_equal(s1, s2)
+
+
+def test_restart_extension_decodes_identically_with_reference(oracle, reference):
+    """Restart-marker ENCODE is an extension (the reference never emits DRI/RSTn).
+    Its oracle is: the reference DECODER decodes it to the same coefficients and samples as the
+    no-restart stream."""
+    img = synth_image(96, 80, 3, 8, seed=5)
+    for (H, V, ri) in [(2, 2, 1), (2, 2, 6), (1, 1, 12), (2, 1, 5), (2, 2, 1000)]:
+        e0, j0, i0 = oracle.encode(img, P=8, H=H, V=V, q=85, optimize=1, restart_interval=0)
+        e1, j1, i1 = oracle.encode(img, P=8, H=H, V=V, q=85, optimize=1, restart_interval=ri)
+        assert e0 == 0 and e1 == 0
+        er, sr, dr = reference.decode(j1)
+        e0r, s0r, d0r = reference.decode(j0)
+        assert er == 0 and e0r == 0
+        assert _same_coefs(dr, d0r)
+        assert np.array_equal(sr, s0r)
+        eo, so, do = oracle.decode(j1)
+        assert eo == 0 and np.array_equal(so, sr)
+
+
+def test_truncated_and_garbage_streams_agree(oracle, reference):
+    img = synth_image(64, 48, 3, 8, seed=9)
+    _, jpg, _ = reference.encode(img, P=8, H=2, V=2, q=80, optimize=1)
+    # ECS cut short but EOI present: remaining blocks stay zero in both
+    cut = jpg[:len(jpg) - 200] + b"\xff\xd9"
+    e1, s1, d1 = oracle.decode(cut)
+    e2, s2, d2 = reference.decode(cut)
+    assert e1 == e2
+    if e1 == 0:
+        assert d1.mblocks > 0
+        assert np.array_equal(s1, s2)
+    # no EOI at all: both fail with an I/O error
+    e1, _, _ = oracle.decode(jpg[:-2])
+    e2, _, _ = reference.decode(jpg[:-2])
+    assert e1 == e2 and e1 != 0
