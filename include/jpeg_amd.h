@@ -1,0 +1,161 @@
+/*
+ * include/jpeg_amd.h -- C-ABI of libjpeg_amd.so, the MI355X (gfx950) hot path of a
+ * baseline-JPEG codec that keeps the semantics of xbarin02/jpeg.
+ *
+ * The reference has no plugin/FFI layer: its boundary is the internal C API on
+ * `struct context` / `struct frame`.  The hot path replaced here is
+ *
+ *   decode:  read_ecs() loop            decoder.c:364-388  (+ read_macroblock :262-362,
+ *                                        read_block coeffs.c:196-254, read_code huffman.c:255-271,
+ *                                        next_bit/read_ecs_byte io.c:18-41,247-274)
+ *            epilogue()                 decoder.c:456-470  (dequantize imgproc.c:32, inverse_dct :172,
+ *                                        conv_blocks_to_frame :233, frame_create frame.c:134,
+ *                                        frame_to_rgb :188, write_frame_body :352)
+ *   encode:  prologue()                 encoder.c:176-193  (read_frame_body frame.c:277, frame_to_ycc :154,
+ *                                        transform_frame_to_components :84, conv_frame_to_blocks
+ *                                        imgproc.c:264, forward_dct :202, quantize :58)
+ *            write_ecs_dry()/write_ecs() encoder.c:525-587 (+ write_block[_dry] coeffs.c:256-363,
+ *                                        write_code huffman.c:274, put_bit/flush_bits io.c:43-87)
+ *
+ * Everything is plain C: pointers and sizes, no C++ or torch types.  Device pointers are
+ * ordinary `void *` obtained from hipMalloc (or torch); `stream` is a hipStream_t passed as
+ * `void *` (NULL = the default stream).  All functions return the reference's RET_* codes
+ * (common.h:15-31).  The library fails loudly (RET_FAILURE_LOGIC_ERROR + message on stderr)
+ * when no HIP device is usable: there is NO CPU fallback.
+ */
+#ifndef JPEG_AMD_H
+#define JPEG_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- error codes: identical values to the reference (common.h:15-31) ------------------ */
+enum {
+	RET_SUCCESS                   = 0x0000,
+	RET_FAILURE_FILE_IO           = 0x1000,
+	RET_FAILURE_FILE_UNSUPPORTED  = 0x1001,
+	RET_FAILURE_FILE_OPEN         = 0x1002,
+	RET_FAILURE_FILE_SEEK         = 0x1003,
+	RET_FAILURE_MEMORY_ALLOCATION = 0x2000,
+	RET_FAILURE_LOGIC_ERROR       = 0x3000,
+	RET_FAILURE_OVERFLOW_ERROR    = 0x3001,
+	RET_FAILURE_NO_MORE_DATA      = 0x4000
+};
+/* device-side conditions for which the reference assert()s or returns -1:
+ *   JPEG_HIP_ERR_DC_RANGE  |DC difference| > 2047               (assert, encoder.c:447)
+ *   JPEG_HIP_ERR_NO_CODE   symbol absent from the Huffman table  (value_to_vlc == -1, huffman.c:252) */
+#define JPEG_HIP_ERR_DC_RANGE 0x5001
+#define JPEG_HIP_ERR_NO_CODE  (-1)
+
+#define JPEG_HIP_MAX_COMP 4
+
+/* Geometry of the frames of one batch (common.c:156-195, frame.c:16-35). */
+typedef struct jpeg_hip_frame_info {
+	int P, X, Y, Nf;                      /* precision, samples per line, lines, components */
+	int id[JPEG_HIP_MAX_COMP];            /* component identifiers, ascending (the reference walks ids 0..255) */
+	int H[JPEG_HIP_MAX_COMP], V[JPEG_HIP_MAX_COMP];
+	int Tq[JPEG_HIP_MAX_COMP], Td[JPEG_HIP_MAX_COMP], Ta[JPEG_HIP_MAX_COMP];
+	int max_H, max_V;
+	int m_x, m_y;                         /* MCUs horizontally / vertically */
+	int size_x, size_y;                   /* padded frame */
+	int bx[JPEG_HIP_MAX_COMP], by[JPEG_HIP_MAX_COMP];   /* blocks per component */
+	int Ri;                               /* restart interval announced by DRI (the reference ignores it) */
+	int blocks_per_mcu;
+	int out_components;                   /* 1 (PGM) or 3 (PPM): frame.c:548-567 */
+	int sample_bytes;                     /* 1, or 2 (big-endian) when P > 8: frame.c:246-257 */
+} jpeg_hip_frame_info;
+
+/* ---- library ---------------------------------------------------------------------------- */
+
+/* Number of usable HIP devices (0 = none: every entry point below then fails loudly). */
+int jpeg_hip_device_count(void);
+const char *jpeg_hip_version(void);
+
+/* ---- batch decoder ------------------------------------------------------------------------
+ * One decoder object owns the device workspace for a batch of frames that share geometry
+ * (Motion JPEG: every frame is an independent SOI..EOI codestream, decoder.c:603-612).
+ *
+ *   prepare  host side: parse_format() (decoder.c:472-659) restated on memory up to SOS, Annex C
+ *            tables (huffman.c:150-178), upload of the codestreams.  Not part of the hot path.
+ *   run      device side, asynchronous on `stream`: byte unstuffing + RSTn segmentation
+ *            (io.c:247-274, decoder.c:622-633), Huffman decode (speculative, self-synchronising
+ *            sub-sequences; per restart interval where markers exist), DC un-prediction
+ *            (decoder.c:351-355), then the fused epilogue (dequantise, IDCT, level shift, up-sampling
+ *            by replication, YCbCr/YCCK -> RGB, roundf, clamp) writing the PPM/PGM body.
+ *   sync     waits and returns per-frame RET_* codes.
+ */
+typedef struct jpeg_hip_decoder jpeg_hip_decoder;
+
+int  jpeg_hip_decoder_create(jpeg_hip_decoder **dec, int device);
+void jpeg_hip_decoder_destroy(jpeg_hip_decoder *dec);
+int  jpeg_hip_decoder_prepare(jpeg_hip_decoder *dec, int nframes,
+                              const uint8_t *const *jpg, const size_t *jpg_len);
+int  jpeg_hip_decoder_info(const jpeg_hip_decoder *dec, jpeg_hip_frame_info *info);
+/* bytes one decoded frame occupies: X*Y*out_components*sample_bytes */
+size_t jpeg_hip_decoder_frame_bytes(const jpeg_hip_decoder *dec);
+int  jpeg_hip_decoder_run(jpeg_hip_decoder *dec, void *d_samples, size_t frame_stride, void *stream);
+int  jpeg_hip_decoder_sync(jpeg_hip_decoder *dec, int *frame_status);
+/* Stage tap for parity tests: coefficients of component k of one frame, in the reference's
+ * int_buffer layout (by*bx blocks of 64 int32, raster order inside a block; coeffs.h:9-11). */
+int  jpeg_hip_decoder_get_coefficients(jpeg_hip_decoder *dec, int frame, int k, int32_t *out);
+/* Per-stage device time of the LAST run, measured with hipEvents on the run's stream.
+ * names/ms arrays of capacity cap; returns the number of stages.  Enabled by
+ * jpeg_hip_decoder_set_timing(dec, 1) (adds one event pair per kernel launch). */
+void jpeg_hip_decoder_set_timing(jpeg_hip_decoder *dec, int on);
+int  jpeg_hip_decoder_get_timing(jpeg_hip_decoder *dec, const char **names, float *ms, int cap);
+/* compressed bytes actually consumed per frame (entropy-coded segment incl. RSTn), for roofline accounting */
+int  jpeg_hip_decoder_ecs_bytes(const jpeg_hip_decoder *dec, size_t *ecs_len);
+
+/* ---- batch encoder ------------------------------------------------------------------------
+ *   configure host side: read_image() set-up (encoder.c:104-152): component sampling, quality
+ *             scaled Annex K.1 tables (encoder.c:38-65), default tables (mjpeg.h), workspace.
+ *   run       device side: fused prologue (sample -> float, edge replication, RGB -> YCbCr, box-mean
+ *             down-sampling, level shift, FDCT, quantise), then entropy coding: [histograms
+ *             (write_ecs_dry) -> K.2 tables ->] per-block bit lengths -> prefix sums -> wavefront bit
+ *             packing -> 0xFF stuffing (write_ecs).  restart_interval > 0 (in MCUs) is an EXTENSION:
+ *             the reference never emits DRI/RSTn.
+ *   sync      waits, returns per-frame RET_* codes and total codestream lengths.
+ */
+typedef struct jpeg_hip_encoder jpeg_hip_encoder;
+
+/* mirrors the reference's command line parameters (struct params, encoder.c:68-88) */
+typedef struct jpeg_hip_params {
+	uint8_t H, V;       /* luma sampling factors, 1 or 2 (-h, -v) */
+	int q;              /* quality 1..100 (-q) */
+	int optimize;       /* optimised Huffman tables (-o) */
+	int restart_interval; /* EXTENSION: MCUs per restart interval, 0 = none */
+} jpeg_hip_params;
+
+int  jpeg_hip_encoder_create(jpeg_hip_encoder **enc, int device);
+void jpeg_hip_encoder_destroy(jpeg_hip_encoder *enc);
+int  jpeg_hip_encoder_configure(jpeg_hip_encoder *enc, int nframes, int X, int Y, int Nf, int P,
+                                const jpeg_hip_params *params);
+int  jpeg_hip_encoder_info(const jpeg_hip_encoder *enc, jpeg_hip_frame_info *info);
+/* d_samples: nframes PPM/PGM bodies (u8, or big-endian u16 when P > 8), frame_stride bytes apart */
+int  jpeg_hip_encoder_run(jpeg_hip_encoder *enc, const void *d_samples, size_t frame_stride, void *stream);
+int  jpeg_hip_encoder_sync(jpeg_hip_encoder *enc, int *frame_status, size_t *jpg_len);
+/* complete codestream (SOI .. EOI) of one frame copied to host memory */
+int  jpeg_hip_encoder_get_jpeg(jpeg_hip_encoder *enc, int frame, uint8_t *out, size_t cap, size_t *len);
+/* device-resident codestream of one frame (valid until the next run) */
+const void *jpeg_hip_encoder_device_jpeg(jpeg_hip_encoder *enc, int frame, size_t *len);
+int  jpeg_hip_encoder_get_coefficients(jpeg_hip_encoder *enc, int frame, int k, int32_t *out);
+void jpeg_hip_encoder_set_timing(jpeg_hip_encoder *enc, int on);
+int  jpeg_hip_encoder_get_timing(jpeg_hip_encoder *enc, const char **names, float *ms, int cap);
+
+/* ---- single-image drop-ins for the reference's top-level entry points ------------------------
+ * Same argument meaning and error behaviour as the functions they replace; the pixel and entropy
+ * work runs on the GPU, marker parsing/production and PPM/PGM I/O on the host. */
+int jpeg_hip_process_jpeg_stream(FILE *stream, const char *path);                 /* decoder.c:661 */
+int jpeg_hip_process_jpeg_file(const char *i_path, const char *o_path);           /* decoder.c:687 */
+int jpeg_hip_process_stream(FILE *i_stream, FILE *o_stream, const jpeg_hip_params *params); /* encoder.c:647 */
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* JPEG_AMD_H */

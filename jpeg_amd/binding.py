@@ -1,0 +1,337 @@
+"""ctypes binding of libjpeg_amd.so (C-ABI declared in include/jpeg_amd.h).
+
+PyTorch is used only as plumbing: device buffers (torch tensors on cuda:N) and the current HIP
+stream.  The codec itself is the shared library; if it cannot be loaded, or no GPU is visible,
+everything here raises -- there is no CPU fallback.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libjpeg_amd.so")
+
+RET_SUCCESS = 0
+RET_FAILURE_FILE_IO = 0x1000
+RET_FAILURE_FILE_UNSUPPORTED = 0x1001
+RET_FAILURE_MEMORY_ALLOCATION = 0x2000
+RET_FAILURE_LOGIC_ERROR = 0x3000
+RET_FAILURE_OVERFLOW_ERROR = 0x3001
+RET_FAILURE_NO_MORE_DATA = 0x4000
+JPEG_HIP_ERR_DC_RANGE = 0x5001
+JPEG_HIP_ERR_NO_CODE = -1
+
+MAX_COMP = 4
+
+EXPORTS = [
+    "jpeg_hip_device_count", "jpeg_hip_version",
+    "jpeg_hip_decoder_create", "jpeg_hip_decoder_destroy", "jpeg_hip_decoder_prepare",
+    "jpeg_hip_decoder_info", "jpeg_hip_decoder_frame_bytes", "jpeg_hip_decoder_run",
+    "jpeg_hip_decoder_sync", "jpeg_hip_decoder_get_coefficients", "jpeg_hip_decoder_set_timing",
+    "jpeg_hip_decoder_get_timing", "jpeg_hip_decoder_ecs_bytes",
+    "jpeg_hip_encoder_create", "jpeg_hip_encoder_destroy", "jpeg_hip_encoder_configure",
+    "jpeg_hip_encoder_info", "jpeg_hip_encoder_run", "jpeg_hip_encoder_sync",
+    "jpeg_hip_encoder_get_jpeg", "jpeg_hip_encoder_device_jpeg", "jpeg_hip_encoder_get_coefficients",
+    "jpeg_hip_encoder_set_timing", "jpeg_hip_encoder_get_timing",
+    "jpeg_hip_process_jpeg_stream", "jpeg_hip_process_jpeg_file", "jpeg_hip_process_stream",
+]
+
+
+class FrameInfo(C.Structure):
+    _fields_ = [
+        ("P", C.c_int), ("X", C.c_int), ("Y", C.c_int), ("Nf", C.c_int),
+        ("id", C.c_int * MAX_COMP), ("H", C.c_int * MAX_COMP), ("V", C.c_int * MAX_COMP),
+        ("Tq", C.c_int * MAX_COMP), ("Td", C.c_int * MAX_COMP), ("Ta", C.c_int * MAX_COMP),
+        ("max_H", C.c_int), ("max_V", C.c_int), ("m_x", C.c_int), ("m_y", C.c_int),
+        ("size_x", C.c_int), ("size_y", C.c_int),
+        ("bx", C.c_int * MAX_COMP), ("by", C.c_int * MAX_COMP),
+        ("Ri", C.c_int), ("blocks_per_mcu", C.c_int), ("out_components", C.c_int), ("sample_bytes", C.c_int),
+    ]
+
+
+class Params(C.Structure):
+    """struct params of the reference (encoder.c:68-76) + the restart-interval extension."""
+    _fields_ = [("H", C.c_uint8), ("V", C.c_uint8), ("q", C.c_int), ("optimize", C.c_int),
+                ("restart_interval", C.c_int)]
+
+
+class JpegError(RuntimeError):
+    def __init__(self, code, what):
+        super().__init__("%s failed: RET 0x%x" % (what, code & 0xffffffff))
+        self.code = code
+
+
+_lib = None
+
+
+def lib():
+    """Load the shared library (loudly)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("%s is missing: run `make` (or __graft_entry__.build()) first" % LIB_PATH)
+        # One HIP runtime per process: the torch wheel bundles its own libamdhip64.so.7.  Import torch
+        # FIRST so that our library binds to that already-loaded runtime (same SONAME) and device
+        # pointers / streams are shared; loading /opt/rocm's copy first leaves torch without a GPU.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
+        L = C.CDLL(LIB_PATH)
+        vp, sz, ip = C.c_void_p, C.c_size_t, C.POINTER(C.c_int)
+        L.jpeg_hip_version.restype = C.c_char_p
+        L.jpeg_hip_decoder_create.argtypes = [C.POINTER(vp), C.c_int]
+        L.jpeg_hip_decoder_destroy.argtypes = [vp]
+        L.jpeg_hip_decoder_destroy.restype = None
+        L.jpeg_hip_decoder_prepare.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(sz)]
+        L.jpeg_hip_decoder_info.argtypes = [vp, C.POINTER(FrameInfo)]
+        L.jpeg_hip_decoder_frame_bytes.argtypes = [vp]
+        L.jpeg_hip_decoder_frame_bytes.restype = sz
+        L.jpeg_hip_decoder_run.argtypes = [vp, vp, sz, vp]
+        L.jpeg_hip_decoder_sync.argtypes = [vp, ip]
+        L.jpeg_hip_decoder_get_coefficients.argtypes = [vp, C.c_int, C.c_int, vp]
+        L.jpeg_hip_decoder_set_timing.argtypes = [vp, C.c_int]
+        L.jpeg_hip_decoder_set_timing.restype = None
+        L.jpeg_hip_decoder_get_timing.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int]
+        L.jpeg_hip_decoder_ecs_bytes.argtypes = [vp, C.POINTER(sz)]
+        L.jpeg_hip_encoder_create.argtypes = [C.POINTER(vp), C.c_int]
+        L.jpeg_hip_encoder_destroy.argtypes = [vp]
+        L.jpeg_hip_encoder_destroy.restype = None
+        L.jpeg_hip_encoder_configure.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Params)]
+        L.jpeg_hip_encoder_info.argtypes = [vp, C.POINTER(FrameInfo)]
+        L.jpeg_hip_encoder_run.argtypes = [vp, vp, sz, vp]
+        L.jpeg_hip_encoder_sync.argtypes = [vp, ip, C.POINTER(sz)]
+        L.jpeg_hip_encoder_get_jpeg.argtypes = [vp, C.c_int, vp, sz, C.POINTER(sz)]
+        L.jpeg_hip_encoder_device_jpeg.argtypes = [vp, C.c_int, C.POINTER(sz)]
+        L.jpeg_hip_encoder_device_jpeg.restype = vp
+        L.jpeg_hip_encoder_get_coefficients.argtypes = [vp, C.c_int, C.c_int, vp]
+        L.jpeg_hip_encoder_set_timing.argtypes = [vp, C.c_int]
+        L.jpeg_hip_encoder_set_timing.restype = None
+        L.jpeg_hip_encoder_get_timing.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int]
+        L.jpeg_hip_process_jpeg_file.argtypes = [C.c_char_p, C.c_char_p]
+        _lib = L
+    return _lib
+
+
+def _torch():
+    import torch
+    if not torch.cuda.is_available():
+        raise RuntimeError("jpeg_amd needs a HIP device (torch.cuda.is_available() is False); no CPU fallback exists")
+    return torch
+
+
+def _stream_ptr(device):
+    torch = _torch()
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _timing(fn, handle):
+    names = (C.c_char_p * 16)()
+    ms = (C.c_float * 16)()
+    n = fn(handle, names, ms, 16)
+    return {names[i].decode(): float(ms[i]) for i in range(n)}
+
+
+class Decoder:
+    """Batch decoder: JPEG codestreams (same geometry) -> PPM/PGM bodies resident in HBM.
+
+    Mirrors read_ecs()+epilogue() of the reference decoder (decoder.c:364-388, 456-470)."""
+
+    def __init__(self, device=0):
+        self.L = lib()
+        self.device = device
+        self.h = C.c_void_p()
+        err = self.L.jpeg_hip_decoder_create(C.byref(self.h), device)
+        if err:
+            raise JpegError(err, "jpeg_hip_decoder_create")
+        self.n = 0
+        self.info = None
+
+    def close(self):
+        if self.h:
+            self.L.jpeg_hip_decoder_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def prepare(self, jpgs):
+        jpgs = [bytes(j) for j in jpgs]
+        self._keep = jpgs
+        n = len(jpgs)
+        ptrs = (C.c_char_p * n)(*jpgs)
+        lens = (C.c_size_t * n)(*[len(j) for j in jpgs])
+        err = self.L.jpeg_hip_decoder_prepare(self.h, n, ptrs, lens)
+        if err:
+            raise JpegError(err, "jpeg_hip_decoder_prepare")
+        self.n = n
+        self.info = FrameInfo()
+        self.L.jpeg_hip_decoder_info(self.h, C.byref(self.info))
+        self.frame_bytes = self.L.jpeg_hip_decoder_frame_bytes(self.h)
+        return self.info
+
+    def set_timing(self, on=True):
+        self.L.jpeg_hip_decoder_set_timing(self.h, int(on))
+
+    def timing(self):
+        return _timing(self.L.jpeg_hip_decoder_get_timing, self.h)
+
+    def alloc_output(self):
+        torch = _torch()
+        return torch.empty((self.n, self.frame_bytes), dtype=torch.uint8, device="cuda:%d" % self.device)
+
+    def run(self, out=None):
+        """Launch the device pipeline on torch's current stream; returns the output tensor."""
+        if out is None:
+            out = self.alloc_output()
+        err = self.L.jpeg_hip_decoder_run(self.h, C.c_void_p(out.data_ptr()), out.stride(0), _stream_ptr(self.device))
+        if err:
+            raise JpegError(err, "jpeg_hip_decoder_run")
+        return out
+
+    def sync(self):
+        st = (C.c_int * self.n)()
+        self.L.jpeg_hip_decoder_sync(self.h, st)
+        return list(st)
+
+    def ecs_bytes(self):
+        v = (C.c_size_t * self.n)()
+        self.L.jpeg_hip_decoder_ecs_bytes(self.h, v)
+        return list(v)
+
+    def coefficients(self, frame):
+        """Per component int32 [by*bx, 64] in the reference's int_buffer layout."""
+        out = []
+        for k in range(self.info.Nf):
+            a = np.zeros((self.info.by[k] * self.info.bx[k], 64), np.int32)
+            err = self.L.jpeg_hip_decoder_get_coefficients(self.h, frame, k, a.ctypes.data_as(C.c_void_p))
+            if err:
+                raise JpegError(err, "jpeg_hip_decoder_get_coefficients")
+            out.append(a)
+        return out
+
+    def to_arrays(self, out):
+        """Output tensor -> list of numpy sample arrays shaped like the PPM/PGM."""
+        i = self.info
+        host = out.cpu().numpy()
+        res = []
+        for f in range(self.n):
+            raw = host[f].tobytes()
+            dt = np.uint8 if i.sample_bytes == 1 else np.dtype(">u2")
+            a = np.frombuffer(raw, dtype=dt).reshape(i.Y, i.X, i.out_components)
+            a = a.astype(np.uint8 if i.sample_bytes == 1 else np.uint16)
+            res.append(a[:, :, 0] if i.out_components == 1 else a)
+        return res
+
+
+class Encoder:
+    """Batch encoder: PPM/PGM bodies resident in HBM -> complete JPEG codestreams in HBM.
+
+    Mirrors prologue()+produce_codestream() of the reference encoder (encoder.c:176-193, 589-645)."""
+
+    def __init__(self, device=0):
+        self.L = lib()
+        self.device = device
+        self.h = C.c_void_p()
+        err = self.L.jpeg_hip_encoder_create(C.byref(self.h), device)
+        if err:
+            raise JpegError(err, "jpeg_hip_encoder_create")
+        self.n = 0
+
+    def close(self):
+        if self.h:
+            self.L.jpeg_hip_encoder_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def configure(self, nframes, X, Y, Nf, P=8, H=2, V=1, q=75, optimize=1, restart_interval=0):
+        prm = Params(H, V, q, optimize, restart_interval)
+        err = self.L.jpeg_hip_encoder_configure(self.h, nframes, X, Y, Nf, P, C.byref(prm))
+        if err:
+            raise JpegError(err, "jpeg_hip_encoder_configure")
+        self.n = nframes
+        self.info = FrameInfo()
+        self.L.jpeg_hip_encoder_info(self.h, C.byref(self.info))
+        self.frame_bytes = X * Y * Nf * (1 if P <= 8 else 2)
+        return self.info
+
+    def set_timing(self, on=True):
+        self.L.jpeg_hip_encoder_set_timing(self.h, int(on))
+
+    def timing(self):
+        return _timing(self.L.jpeg_hip_encoder_get_timing, self.h)
+
+    def upload(self, images):
+        """List of (Y,X[,3]) integer arrays -> device tensor of PPM/PGM bodies."""
+        torch = _torch()
+        P = self.info.P
+        bodies = [np.asarray(a).astype(np.uint8).tobytes() if P <= 8 else np.asarray(a).astype(">u2").tobytes()
+                  for a in images]
+        host = np.frombuffer(b"".join(bodies), np.uint8).reshape(len(images), self.frame_bytes)
+        return torch.from_numpy(host.copy()).to("cuda:%d" % self.device)
+
+    def run(self, samples):
+        err = self.L.jpeg_hip_encoder_run(self.h, C.c_void_p(samples.data_ptr()), samples.stride(0),
+                                          _stream_ptr(self.device))
+        if err:
+            raise JpegError(err, "jpeg_hip_encoder_run")
+
+    def sync(self):
+        st = (C.c_int * self.n)()
+        ln = (C.c_size_t * self.n)()
+        self.L.jpeg_hip_encoder_sync(self.h, st, ln)
+        return list(st), list(ln)
+
+    def jpeg(self, frame, length):
+        buf = C.create_string_buffer(length)
+        n = C.c_size_t()
+        err = self.L.jpeg_hip_encoder_get_jpeg(self.h, frame, buf, length, C.byref(n))
+        if err:
+            raise JpegError(err, "jpeg_hip_encoder_get_jpeg")
+        return buf.raw[:n.value]
+
+    def coefficients(self, frame):
+        out = []
+        for k in range(self.info.Nf):
+            a = np.zeros((self.info.by[k] * self.info.bx[k], 64), np.int32)
+            err = self.L.jpeg_hip_encoder_get_coefficients(self.h, frame, k, a.ctypes.data_as(C.c_void_p))
+            if err:
+                raise JpegError(err, "jpeg_hip_encoder_get_coefficients")
+            out.append(a)
+        return out
+
+
+def decode(jpgs, device=0):
+    """Convenience: list of codestreams -> (list of sample arrays, list of RET codes)."""
+    d = Decoder(device)
+    try:
+        d.prepare(jpgs)
+        out = d.run()
+        st = d.sync()
+        return d.to_arrays(out), st
+    finally:
+        d.close()
+
+
+def encode(images, P=8, H=2, V=1, q=75, optimize=1, device=0):
+    """Convenience: list of same-shaped images -> (list of JPEG bytes, list of RET codes)."""
+    a0 = np.asarray(images[0])
+    Y, X = a0.shape[:2]
+    Nf = 1 if a0.ndim == 2 else a0.shape[2]
+    e = Encoder(device)
+    try:
+        e.configure(len(images), X, Y, Nf, P, H, V, q, optimize)
+        e.run(e.upload(images))
+        st, ln = e.sync()
+        return [e.jpeg(f, ln[f]) if st[f] == 0 else None for f in range(len(images))], st
+    finally:
+        e.close()

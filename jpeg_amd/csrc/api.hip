@@ -1,0 +1,1072 @@
+// jpeg_amd/csrc/api.hip -- the C-ABI of libjpeg_amd.so (declared in include/jpeg_amd.h).
+//
+// Host orchestration only: header parsing / production (codestream.cpp), workspace management and
+// kernel launches.  Everything pixel- or coefficient-sized stays resident in HBM between stages.
+// There is no CPU fallback: without a usable HIP device every entry point fails loudly.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <ctype.h>
+#include <vector>
+#include <string>
+#include "../../include/jpeg_amd.h"
+#include "common.hpp"
+#include "codestream.hpp"
+#include "kernels.hpp"
+
+#define HIPCHK(call)                                                                         \
+	do {                                                                                     \
+		hipError_t e_ = (call);                                                              \
+		if (e_ != hipSuccess) {                                                              \
+			fprintf(stderr, "jpeg_amd: %s failed: %s (%s:%d)\n", #call, hipGetErrorString(e_), \
+			        __FILE__, __LINE__);                                                     \
+			return e_ == hipErrorOutOfMemory ? RET_FAILURE_MEMORY_ALLOCATION : RET_FAILURE_LOGIC_ERROR; \
+		}                                                                                    \
+	} while (0)
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+extern "C" int jpeg_hip_device_count(void)
+{
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess) {
+		return 0;
+	}
+	return n;
+}
+
+extern "C" const char *jpeg_hip_version(void) { return "jpeg_amd 0.1 (gfx950)"; }
+
+static int require_device(int device)
+{
+	int n = jpeg_hip_device_count();
+	if (n <= 0) {
+		fprintf(stderr, "jpeg_amd: no HIP device available -- this library has no CPU fallback\n");
+		return RET_FAILURE_LOGIC_ERROR;
+	}
+	if (device < 0 || device >= n) {
+		fprintf(stderr, "jpeg_amd: device %d out of range (%d devices)\n", device, n);
+		return RET_FAILURE_LOGIC_ERROR;
+	}
+	HIPCHK(hipSetDevice(device));
+	return RET_SUCCESS;
+}
+
+static void fill_info(const JhGeom &g, jpeg_hip_frame_info *o)
+{
+	memset(o, 0, sizeof *o);
+	o->P = g.P; o->X = g.X; o->Y = g.Y; o->Nf = g.Nf;
+	for (int k = 0; k < g.ncomp; ++k) {
+		o->id[k] = g.id[k]; o->H[k] = g.H[k]; o->V[k] = g.V[k];
+		o->Tq[k] = g.Tq[k]; o->Td[k] = g.Td[k]; o->Ta[k] = g.Ta[k];
+		o->bx[k] = g.bx[k]; o->by[k] = g.by[k];
+	}
+	o->max_H = g.max_H; o->max_V = g.max_V; o->m_x = g.m_x; o->m_y = g.m_y;
+	o->size_x = g.size_x; o->size_y = g.size_y; o->Ri = g.Ri;
+	o->blocks_per_mcu = g.B; o->out_components = g.out_comps; o->sample_bytes = g.sample_bytes;
+}
+
+// scan-order / zig-zag int16 coefficients of one frame -> the reference's int_buffer layout of component k
+static void coefs_to_reference_layout(const JhGeom &g, const int16_t *fc, int k, int32_t *out)
+{
+	for (int by = 0; by < g.by[k]; ++by) {
+		for (int bx = 0; bx < g.bx[k]; ++bx) {
+			const int mx = bx / g.H[k], h = bx % g.H[k], my = by / g.V[k], v = by % g.V[k];
+			const size_t blk = (size_t)(my * g.m_x + mx) * g.B + g.comp_first[k] + v * g.H[k] + h;
+			int32_t *dst = out + ((size_t)by * g.bx[k] + bx) * 64;
+			for (int z = 0; z < 64; ++z) {
+				dst[jh_zigzag[z]] = fc[blk * 64 + z];
+			}
+		}
+	}
+}
+
+struct StageTimer {
+	bool on = false;
+	std::vector<std::string> names;
+	std::vector<hipEvent_t> ev;       // 2 per stage
+	size_t used = 0;
+	void begin(const char *name, hipStream_t s)
+	{
+		if (!on) {
+			return;
+		}
+		if (used + 2 > ev.size()) {
+			hipEvent_t a, b;
+			hipEventCreate(&a);
+			hipEventCreate(&b);
+			ev.push_back(a);
+			ev.push_back(b);
+		}
+		names.push_back(name);
+		hipEventRecord(ev[used], s);
+	}
+	void end(hipStream_t s)
+	{
+		if (!on) {
+			return;
+		}
+		hipEventRecord(ev[used + 1], s);
+		used += 2;
+	}
+	void reset() { used = 0; names.clear(); }
+	int collect(const char **n, float *ms, int cap)
+	{
+		int k = 0;
+		for (size_t i = 0; i + 1 < used && k < cap && (size_t)k < names.size(); i += 2, ++k) {
+			hipEventSynchronize(ev[i + 1]);
+			float t = 0.f;
+			hipEventElapsedTime(&t, ev[i], ev[i + 1]);
+			n[k] = names[k].c_str();
+			ms[k] = t;
+		}
+		return k;
+	}
+	~StageTimer()
+	{
+		for (hipEvent_t e : ev) {
+			hipEventDestroy(e);
+		}
+	}
+};
+
+// ======================================================================================= decoder
+
+struct jpeg_hip_decoder {
+	int device = 0;
+	int nframes = 0;
+	JhGeom g;
+	std::vector<JhDecFrame> frames;
+	std::vector<JhDecState> state;
+	std::vector<int> parse_err;
+	std::vector<size_t> ecs_len;
+	// device
+	uint8_t *d_raw = nullptr, *d_cs = nullptr;
+	uint32_t *d_seg = nullptr, *d_chunk_kept = nullptr, *d_chunk_rst = nullptr;
+	JhSubInfo *d_sub = nullptr;
+	JhSubStart *d_start = nullptr;
+	JhDecFrame *d_frames = nullptr;
+	JhDecState *d_state = nullptr;
+	JhHuffLut *d_luts = nullptr;
+	JhQuant *d_quant = nullptr;
+	int16_t *d_coefs = nullptr;
+	size_t raw_bytes = 0, cs_bytes = 0, seg_entries = 0, chunk_entries = 0, sub_entries = 0;
+	JhDecodeWork work;
+	void *last_out = nullptr;
+	size_t last_stride = 0;
+	hipStream_t last_stream = nullptr;
+	bool ran = false;
+	StageTimer timer;
+
+	void release()
+	{
+		hipFree(d_raw); hipFree(d_cs); hipFree(d_seg); hipFree(d_chunk_kept); hipFree(d_chunk_rst);
+		hipFree(d_sub); hipFree(d_start); hipFree(d_frames); hipFree(d_state); hipFree(d_luts);
+		hipFree(d_quant); hipFree(d_coefs);
+		d_raw = d_cs = nullptr; d_seg = d_chunk_kept = d_chunk_rst = nullptr;
+		d_sub = nullptr; d_start = nullptr; d_frames = nullptr; d_state = nullptr; d_luts = nullptr;
+		d_quant = nullptr; d_coefs = nullptr;
+	}
+};
+
+extern "C" int jpeg_hip_decoder_create(jpeg_hip_decoder **dec, int device)
+{
+	*dec = nullptr;
+	int err = require_device(device);
+	if (err) {
+		return err;
+	}
+	jpeg_hip_decoder *d = new jpeg_hip_decoder();
+	d->device = device;
+	memset(&d->g, 0, sizeof d->g);
+	*dec = d;
+	return RET_SUCCESS;
+}
+
+extern "C" void jpeg_hip_decoder_destroy(jpeg_hip_decoder *dec)
+{
+	if (dec) {
+		hipSetDevice(dec->device);
+		dec->release();
+		delete dec;
+	}
+}
+
+static bool same_geometry(const JhGeom &a, const JhGeom &b)
+{
+	if (a.P != b.P || a.X != b.X || a.Y != b.Y || a.Nf != b.Nf || a.ncomp != b.ncomp) {
+		return false;
+	}
+	for (int k = 0; k < a.ncomp; ++k) {
+		if (a.H[k] != b.H[k] || a.V[k] != b.V[k] || a.scan_order[k] != b.scan_order[k]) {
+			return false;
+		}
+	}
+	return true;
+}
+
+extern "C" int jpeg_hip_decoder_prepare(jpeg_hip_decoder *dec, int nframes,
+                                        const uint8_t *const *jpg, const size_t *jpg_len)
+{
+	if (!dec || nframes <= 0) {
+		return RET_FAILURE_LOGIC_ERROR;
+	}
+	HIPCHK(hipSetDevice(dec->device));
+	dec->release();
+	dec->ran = false;
+	dec->nframes = nframes;
+	dec->frames.assign(nframes, JhDecFrame());
+	dec->state.assign(nframes, JhDecState());
+	dec->parse_err.assign(nframes, 0);
+	dec->ecs_len.assign(nframes, 0);
+
+	std::vector<JhHeader> hdr(nframes);
+	std::vector<JhHuffLut> luts;
+	std::vector<JhQuant> quant(nframes);
+	bool have_geom = false;
+	size_t raw_off = 0, cs_off = 0, seg_off = 0, chunk_off = 0, sub_off = 0;
+	uint32_t max_chunks = 1, max_subs = 1, max_luts = 1;
+	std::vector<size_t> file_off(nframes);
+
+	for (int f = 0; f < nframes; ++f) {
+		JhHeader &h = hdr[f];
+		int err = jh_parse_headers(jpg[f], jpg_len[f], &h);
+		if (!err) {
+			// the GPU path handles one scan that interleaves all components in frame order
+			// (everything the reference encoder and baseline encoders emit); the reference's
+			// multi-scan walk (decoder.c:274-302 on colour files) is listed under "next".
+			if (h.Ns != h.g.ncomp) {
+				err = RET_FAILURE_FILE_UNSUPPORTED;
+			}
+			for (int j = 0; j < h.Ns && !err; ++j) {
+				h.g.scan_order[j] = h.scan_comp[j];
+			}
+		}
+		if (!err) {
+			err = jh_finish_geometry(&h.g);
+		}
+		if (!err) {
+			if (!have_geom) {
+				dec->g = h.g;
+				have_geom = true;
+			} else if (!same_geometry(dec->g, h.g)) {
+				err = RET_FAILURE_FILE_UNSUPPORTED;   // one batch = one geometry
+			}
+		}
+		dec->parse_err[f] = err;
+		file_off[f] = raw_off;
+		JhDecFrame &fr = dec->frames[f];
+		memset(&fr, 0, sizeof fr);
+		if (err) {
+			// keep a harmless empty frame so that the grids stay rectangular
+			fr.raw_begin = fr.raw_end = (uint32_t)raw_off;
+			fr.cs_off = (uint32_t)cs_off;
+			fr.sub_off = (uint32_t)sub_off;
+			fr.sub_cap = 1;
+			fr.seg_off = (uint32_t)seg_off;
+			fr.seg_cap = 4;
+			fr.chunk_off = (uint32_t)chunk_off;
+			fr.nchunk = 0;
+			fr.lut_off = (uint32_t)luts.size();
+			fr.n_lut = 0;
+			cs_off += 64;
+			sub_off += 1;
+			seg_off += 4;
+			continue;
+		}
+		const size_t flen = jpg_len[f];
+		fr.raw_begin = (uint32_t)(raw_off + h.ecs_offset);
+		fr.raw_end = (uint32_t)(raw_off + flen);
+		const size_t ecs = flen - h.ecs_offset;
+		fr.cs_off = (uint32_t)cs_off;
+		const size_t cs_cap = align_up(ecs + 32, 64);
+		fr.sub_off = (uint32_t)sub_off;
+		fr.sub_cap = (uint32_t)(cs_cap / JH_SUBSEQ_BYTES + 2);
+		fr.seg_off = (uint32_t)seg_off;
+		const int Ri = h.g.Ri;
+		fr.seg_cap = (uint32_t)((Ri > 0 ? (h.g.nmcu + Ri - 1) / Ri : 1) + 64);
+		fr.chunk_off = (uint32_t)chunk_off;
+		fr.nchunk = (uint32_t)((fr.raw_end + 4095) / 4096 - fr.raw_begin / 4096);
+		// Huffman tables used by this frame's scan -> LDS slots
+		int slot_of[2][4] = {{-1, -1, -1, -1}, {-1, -1, -1, -1}};
+		fr.lut_off = (uint32_t)luts.size();
+		for (int k = 0; k < h.g.ncomp && !err; ++k) {
+			const int ids[2] = {h.g.Td[k], h.g.Ta[k]};
+			for (int tc = 0; tc < 2 && !err; ++tc) {
+				if (slot_of[tc][ids[tc]] < 0) {
+					JhHuffLut l;
+					err = jh_build_declut(&h.ht[tc][ids[tc]], &l);
+					slot_of[tc][ids[tc]] = (int)fr.n_lut++;
+					luts.push_back(l);
+				}
+			}
+		}
+		if (err) {
+			dec->parse_err[f] = err;
+			fr.nchunk = 0;
+			fr.raw_end = fr.raw_begin;
+		}
+		for (int b = 0; b < h.g.B; ++b) {
+			const int k = h.g.blk_comp[b];
+			fr.blk_dc[b] = (uint8_t)slot_of[0][h.g.Td[k]];
+			fr.blk_ac[b] = (uint8_t)slot_of[1][h.g.Ta[k]];
+		}
+		for (int t = 0; t < 4; ++t) {
+			for (int z = 0; z < 64; ++z) {
+				quant[f].q[t][z] = h.Q[t][jh_zigzag[z]];
+			}
+		}
+		max_chunks = fr.nchunk > max_chunks ? fr.nchunk : max_chunks;
+		max_subs = fr.sub_cap > max_subs ? fr.sub_cap : max_subs;
+		max_luts = fr.n_lut > max_luts ? fr.n_lut : max_luts;
+		raw_off = align_up(raw_off + flen + 32, 4096);   // chunk aligned: frames never share a chunk
+		cs_off += cs_cap;
+		sub_off += fr.sub_cap;
+		seg_off += fr.seg_cap;
+		chunk_off += fr.nchunk;
+		if (raw_off > 0xf0000000ull || cs_off > 0xf0000000ull) {
+			return RET_FAILURE_OVERFLOW_ERROR;               // 32-bit offsets: split the batch
+		}
+	}
+	if (!have_geom) {
+		// nothing decodable: report the first parse error
+		return dec->parse_err[0] ? dec->parse_err[0] : RET_FAILURE_FILE_UNSUPPORTED;
+	}
+	if (raw_off == 0) {
+		raw_off = 4096;
+	}
+	dec->raw_bytes = raw_off + 4096;
+	dec->cs_bytes = cs_off + 64;
+	dec->seg_entries = seg_off + 4;
+	dec->chunk_entries = chunk_off + 4;
+	dec->sub_entries = sub_off + 4;
+	if (luts.empty()) {
+		luts.push_back(JhHuffLut());
+	}
+
+	HIPCHK(hipMalloc((void **)&dec->d_raw, dec->raw_bytes));
+	HIPCHK(hipMalloc((void **)&dec->d_cs, dec->cs_bytes));
+	HIPCHK(hipMalloc((void **)&dec->d_seg, dec->seg_entries * 4));
+	HIPCHK(hipMalloc((void **)&dec->d_chunk_kept, dec->chunk_entries * 4));
+	HIPCHK(hipMalloc((void **)&dec->d_chunk_rst, dec->chunk_entries * 4));
+	HIPCHK(hipMalloc((void **)&dec->d_sub, dec->sub_entries * sizeof(JhSubInfo)));
+	HIPCHK(hipMalloc((void **)&dec->d_start, dec->sub_entries * sizeof(JhSubStart)));
+	HIPCHK(hipMalloc((void **)&dec->d_frames, nframes * sizeof(JhDecFrame)));
+	HIPCHK(hipMalloc((void **)&dec->d_state, nframes * sizeof(JhDecState)));
+	HIPCHK(hipMalloc((void **)&dec->d_luts, luts.size() * sizeof(JhHuffLut)));
+	HIPCHK(hipMalloc((void **)&dec->d_quant, nframes * sizeof(JhQuant)));
+	HIPCHK(hipMalloc((void **)&dec->d_coefs, (size_t)nframes * dec->g.nblk * 64 * sizeof(int16_t)));
+	HIPCHK(hipMemset(dec->d_raw, 0, dec->raw_bytes));
+	HIPCHK(hipMemset(dec->d_cs, 0, dec->cs_bytes));
+	HIPCHK(hipMemset(dec->d_seg, 0, dec->seg_entries * 4));
+	for (int f = 0; f < nframes; ++f) {
+		if (dec->parse_err[f] == 0) {
+			HIPCHK(hipMemcpy(dec->d_raw + file_off[f], jpg[f], jpg_len[f], hipMemcpyHostToDevice));
+		}
+	}
+	HIPCHK(hipMemcpy(dec->d_frames, dec->frames.data(), nframes * sizeof(JhDecFrame), hipMemcpyHostToDevice));
+	HIPCHK(hipMemcpy(dec->d_luts, luts.data(), luts.size() * sizeof(JhHuffLut), hipMemcpyHostToDevice));
+	HIPCHK(hipMemcpy(dec->d_quant, quant.data(), nframes * sizeof(JhQuant), hipMemcpyHostToDevice));
+
+	JhDecodeWork &w = dec->work;
+	w.raw = dec->d_raw;
+	w.cs = dec->d_cs;
+	w.seg_start = dec->d_seg;
+	w.chunk_kept = dec->d_chunk_kept;
+	w.chunk_rst = dec->d_chunk_rst;
+	w.sub = dec->d_sub;
+	w.start = dec->d_start;
+	w.frames = dec->d_frames;
+	w.state = dec->d_state;
+	w.luts = dec->d_luts;
+	w.coefs = dec->d_coefs;
+	w.nframes = nframes;
+	w.max_chunks = max_chunks;
+	w.max_subs = max_subs;
+	w.max_luts = max_luts;
+	return RET_SUCCESS;
+}
+
+extern "C" int jpeg_hip_decoder_info(const jpeg_hip_decoder *dec, jpeg_hip_frame_info *info)
+{
+	if (!dec || dec->nframes == 0) {
+		return RET_FAILURE_LOGIC_ERROR;
+	}
+	fill_info(dec->g, info);
+	return RET_SUCCESS;
+}
+
+extern "C" size_t jpeg_hip_decoder_frame_bytes(const jpeg_hip_decoder *dec)
+{
+	const JhGeom &g = dec->g;
+	return (size_t)g.X * g.Y * g.out_comps * g.sample_bytes;
+}
+
+__global__ void k_dec_init(JhDecState *st, int n)
+{
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) {
+		JhDecState s;
+		memset(&s, 0, sizeof s);
+		s.term_pos = 0xffffffffu;
+		st[i] = s;
+	}
+}
+
+__global__ void k_dec_reset_rounds(JhDecState *st, int n)
+{
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) {
+		for (int r = 0; r <= JH_SYNC_ITERS; ++r) {
+			st[i].changed[r] = 0;
+		}
+	}
+}
+
+static int decoder_launch(jpeg_hip_decoder *dec, hipStream_t s, bool resync_only)
+{
+	const JhDecodeWork &w = dec->work;
+	const size_t coef_bytes = (size_t)dec->nframes * dec->g.nblk * 64 * sizeof(int16_t);
+	if (!resync_only) {
+		dec->timer.begin("unstuff", s);
+		hipLaunchKernelGGL(k_dec_init, dim3((dec->nframes + 63) / 64), dim3(64), 0, s, dec->d_state, dec->nframes);
+		if (jh_launch_ecs_unstuff(w, s)) {
+			return RET_FAILURE_LOGIC_ERROR;
+		}
+		dec->timer.end(s);
+	} else {
+		hipLaunchKernelGGL(k_dec_reset_rounds, dim3((dec->nframes + 63) / 64), dim3(64), 0, s, dec->d_state, dec->nframes);
+	}
+	dec->timer.begin("coef_clear", s);
+	// alloc_buffers() zero-fills int_buffer (common.c:129): blocks the stream never reaches stay 0
+	HIPCHK(hipMemsetAsync(dec->d_coefs, 0, coef_bytes, s));
+	dec->timer.end(s);
+	dec->timer.begin("huffman", s);
+	if (jh_launch_huff_decode(w, dec->g, s, resync_only ? 1 : 0)) {
+		return RET_FAILURE_LOGIC_ERROR;
+	}
+	dec->timer.end(s);
+	dec->timer.begin("pixels", s);
+	if (jh_launch_decode_pixels(dec->g, dec->nframes, dec->d_coefs, dec->d_quant, dec->last_out, dec->last_stride, s)) {
+		return RET_FAILURE_LOGIC_ERROR;
+	}
+	dec->timer.end(s);
+	return RET_SUCCESS;
+}
+
+extern "C" int jpeg_hip_decoder_run(jpeg_hip_decoder *dec, void *d_samples, size_t frame_stride, void *stream)
+{
+	if (!dec || dec->nframes == 0 || !d_samples) {
+		return RET_FAILURE_LOGIC_ERROR;
+	}
+	if (frame_stride < jpeg_hip_decoder_frame_bytes(dec)) {
+		return RET_FAILURE_LOGIC_ERROR;
+	}
+	HIPCHK(hipSetDevice(dec->device));
+	dec->last_out = d_samples;
+	dec->last_stride = frame_stride;
+	dec->last_stream = (hipStream_t)stream;
+	dec->timer.reset();
+	int err = decoder_launch(dec, dec->last_stream, false);
+	dec->ran = err == RET_SUCCESS;
+	return err;
+}
+
+extern "C" int jpeg_hip_decoder_sync(jpeg_hip_decoder *dec, int *frame_status)
+{
+	if (!dec || !dec->ran) {
+		return RET_FAILURE_LOGIC_ERROR;
+	}
+	HIPCHK(hipSetDevice(dec->device));
+	for (int attempt = 0;; ++attempt) {
+		HIPCHK(hipStreamSynchronize(dec->last_stream));
+		HIPCHK(hipMemcpy(dec->state.data(), dec->d_state, dec->nframes * sizeof(JhDecState), hipMemcpyDeviceToHost));
+		bool pending = false;
+		for (int f = 0; f < dec->nframes; ++f) {
+			if (dec->parse_err[f] == 0 && (dec->state[f].status & JH_ST_NOT_CONVERGED)) {
+				pending = true;
+			}
+		}
+		if (!pending) {
+			break;
+		}
+		if (attempt >= 4096) {
+			return RET_FAILURE_LOGIC_ERROR;
+		}
+		// rare: a chain needed more than JH_SYNC_ITERS rounds to fall into step; run more rounds
+		int err = decoder_launch(dec, dec->last_stream, true);
+		if (err) {
+			return err;
+		}
+	}
+	int worst = RET_SUCCESS;
+	for (int f = 0; f < dec->nframes; ++f) {
+		int st = dec->parse_err[f];
+		if (!st) {
+			const JhDecState &ds = dec->state[f];
+			const JhDecFrame &fr = dec->frames[f];
+			dec->ecs_len[f] = ds.term_pos - fr.raw_begin;
+			if (ds.status & JH_ST_SEG_OVERFLOW) {
+				st = RET_FAILURE_FILE_UNSUPPORTED;
+			} else if (ds.term_pos >= fr.raw_end) {
+				st = RET_FAILURE_FILE_IO;            // no EOI: read_marker() hits end of file (io.c:197)
+			} else if (ds.term_marker != 0xd9) {
+				st = RET_FAILURE_FILE_UNSUPPORTED;   // further scans / tables after this ECS: not on the GPU path
+			}
+		}
+		if (frame_status) {
+			frame_status[f] = st;
+		}
+		if (st && !worst) {
+			worst = st;
+		}
+	}
+	return worst;
+}
+
+extern "C" int jpeg_hip_decoder_get_coefficients(jpeg_hip_decoder *dec, int frame, int k, int32_t *out)
+{
+	if (!dec || !dec->ran || frame < 0 || frame >= dec->nframes || k < 0 || k >= dec->g.ncomp) {
+		return RET_FAILURE_LOGIC_ERROR;
+	}
+	HIPCHK(hipSetDevice(dec->device));
+	const size_t n = (size_t)dec->g.nblk * 64;
+	std::vector<int16_t> fc(n);
+	HIPCHK(hipMemcpy(fc.data(), dec->d_coefs + (size_t)frame * n, n * sizeof(int16_t), hipMemcpyDeviceToHost));
+	coefs_to_reference_layout(dec->g, fc.data(), k, out);
+	return RET_SUCCESS;
+}
+
+extern "C" void jpeg_hip_decoder_set_timing(jpeg_hip_decoder *dec, int on) { dec->timer.on = on != 0; }
+
+extern "C" int jpeg_hip_decoder_get_timing(jpeg_hip_decoder *dec, const char **names, float *ms, int cap)
+{
+	hipSetDevice(dec->device);
+	return dec->timer.collect(names, ms, cap);
+}
+
+extern "C" int jpeg_hip_decoder_ecs_bytes(const jpeg_hip_decoder *dec, size_t *ecs_len)
+{
+	for (int f = 0; f < dec->nframes; ++f) {
+		ecs_len[f] = dec->ecs_len[f];
+	}
+	return RET_SUCCESS;
+}
+
+// ======================================================================================= encoder
+
+struct jpeg_hip_encoder {
+	int device = 0;
+	int nframes = 0;
+	JhGeom g;
+	jpeg_hip_params prm;
+	uint16_t Q[4][64];
+	JhHuffSpec ht[2][4];
+	std::vector<std::vector<uint8_t>> headers;   // per frame
+	std::vector<uint32_t> hdr_len;
+	std::vector<JhEncState> state;
+	// device
+	JhQuant *d_quant = nullptr;
+	int16_t *d_coefs = nullptr;
+	JhHuffEnc *d_codes = nullptr;
+	uint32_t *d_hist = nullptr, *d_wg_bits = nullptr, *d_us = nullptr, *d_chunk_ff = nullptr, *d_hdr_len = nullptr;
+	uint16_t *d_bitlen = nullptr;
+	uint8_t *d_out = nullptr;
+	JhEncState *d_state = nullptr;
+	JhEncodeWork work;
+	hipStream_t last_stream = nullptr;
+	bool ran = false;
+	StageTimer timer;
+
+	void release()
+	{
+		hipFree(d_quant); hipFree(d_coefs); hipFree(d_codes); hipFree(d_hist); hipFree(d_wg_bits);
+		hipFree(d_us); hipFree(d_chunk_ff); hipFree(d_hdr_len); hipFree(d_bitlen); hipFree(d_out); hipFree(d_state);
+		d_quant = nullptr; d_coefs = nullptr; d_codes = nullptr; d_hist = d_wg_bits = d_us = d_chunk_ff = d_hdr_len = nullptr;
+		d_bitlen = nullptr; d_out = nullptr; d_state = nullptr;
+	}
+};
+
+extern "C" int jpeg_hip_encoder_create(jpeg_hip_encoder **enc, int device)
+{
+	*enc = nullptr;
+	int err = require_device(device);
+	if (err) {
+		return err;
+	}
+	jpeg_hip_encoder *e = new jpeg_hip_encoder();
+	e->device = device;
+	memset(&e->g, 0, sizeof e->g);
+	*enc = e;
+	return RET_SUCCESS;
+}
+
+extern "C" void jpeg_hip_encoder_destroy(jpeg_hip_encoder *enc)
+{
+	if (enc) {
+		hipSetDevice(enc->device);
+		enc->release();
+		delete enc;
+	}
+}
+
+struct TableSet {
+	JhHuffSpec t[2][4];
+};
+
+static int upload_codes_and_headers(jpeg_hip_encoder *e, int f0, int f1, const TableSet *specs, hipStream_t s)
+{
+	// specs == nullptr: every frame uses e->ht
+	std::vector<JhHuffEnc> codes((size_t)(f1 - f0) * 4);
+	for (int f = f0; f < f1; ++f) {
+		const JhHuffSpec(&ht)[2][4] = specs ? specs[f - f0].t : e->ht;
+		for (int tc = 0; tc < 2; ++tc) {
+			for (int th = 0; th < 2; ++th) {
+				int err = jh_build_enccodes(&ht[tc][th], &codes[(size_t)(f - f0) * 4 + tc * 2 + th]);
+				if (err) {
+					return err;
+				}
+			}
+		}
+		jh_produce_headers(e->g, e->Q, ht, e->prm.restart_interval, &e->headers[f]);
+		e->hdr_len[f] = (uint32_t)e->headers[f].size();
+		if (e->hdr_len[f] > 2048) {
+			return RET_FAILURE_LOGIC_ERROR;
+		}
+		HIPCHK(hipMemcpyAsync(e->d_out + (size_t)f * e->work.out_stride, e->headers[f].data(), e->hdr_len[f],
+		                      hipMemcpyHostToDevice, s));
+	}
+	HIPCHK(hipMemcpyAsync(e->d_codes + (size_t)f0 * 4, codes.data(), codes.size() * sizeof(JhHuffEnc), hipMemcpyHostToDevice, s));
+	HIPCHK(hipMemcpyAsync(e->d_hdr_len + f0, e->hdr_len.data() + f0, (size_t)(f1 - f0) * 4, hipMemcpyHostToDevice, s));
+	HIPCHK(hipStreamSynchronize(s));   // host vectors above are transient
+	return RET_SUCCESS;
+}
+
+extern "C" int jpeg_hip_encoder_configure(jpeg_hip_encoder *enc, int nframes, int X, int Y, int Nf, int P,
+                                          const jpeg_hip_params *params)
+{
+	if (!enc || !params || nframes <= 0) {
+		return RET_FAILURE_LOGIC_ERROR;
+	}
+	HIPCHK(hipSetDevice(enc->device));
+	enc->release();
+	enc->ran = false;
+	if ((Nf != 1 && Nf != 3) || X <= 0 || Y <= 0 || X > 65535 || Y > 65535) {
+		return RET_FAILURE_FILE_UNSUPPORTED;               // encoder.c:147-148
+	}
+	if (Nf == 3 && (params->H < 1 || params->H > 2 || params->V < 1 || params->V > 2)) {
+		return RET_FAILURE_FILE_UNSUPPORTED;               // assert in the reference (encoder.c:123-124)
+	}
+	if (params->restart_interval != 0) {
+		return RET_FAILURE_FILE_UNSUPPORTED;               // restart-marker ENCODE: next
+	}
+	enc->prm = *params;
+	enc->nframes = nframes;
+	JhGeom &g = enc->g;
+	memset(&g, 0, sizeof g);
+	g.P = P; g.X = X; g.Y = Y; g.Nf = Nf; g.ncomp = Nf;
+	// read_image() component set-up (encoder.c:109-146): ids 1..3, luma H x V, chroma 1 x 1
+	for (int k = 0; k < Nf; ++k) {
+		g.id[k] = k + 1;
+		g.H[k] = (k == 0 && Nf == 3) ? params->H : 1;
+		g.V[k] = (k == 0 && Nf == 3) ? params->V : 1;
+		g.Tq[k] = g.Td[k] = g.Ta[k] = k == 0 ? 0 : 1;
+		g.scan_order[k] = k;
+	}
+	int err = jh_finish_geometry(&g);
+	if (err) {
+		return err;
+	}
+	memset(enc->Q, 0, sizeof enc->Q);
+	for (int t = 0; t < 4; ++t) {
+		for (int i = 0; i < 64; ++i) {
+			enc->Q[t][i] = 1;
+		}
+	}
+	jh_set_qtable(enc->Q[0], 0, params->q);                // encoder.c:151-152
+	jh_set_qtable(enc->Q[1], 1, params->q);
+	for (int tc = 0; tc < 2; ++tc) {
+		for (int th = 0; th < 4; ++th) {
+			jh_default_table(tc, th & 1, &enc->ht[tc][th]);
+		}
+	}
+
+	JhEncodeWork &w = enc->work;
+	memset(&w, 0, sizeof w);
+	w.nframes = nframes;
+	w.nwg = (g.nblk + 255) / 256;
+	const size_t raw = (size_t)X * Y * Nf * g.sample_bytes;
+	w.us_stride = align_up(raw + (size_t)g.nblk * 4 + 65536, 4096);
+	w.nchunk = (int)(w.us_stride / 4096);
+	w.out_stride = align_up(4096 + w.us_stride + w.us_stride / 8, 4096);
+	w.restart_interval = params->restart_interval;
+
+	HIPCHK(hipMalloc((void **)&enc->d_quant, nframes * sizeof(JhQuant)));
+	HIPCHK(hipMalloc((void **)&enc->d_coefs, (size_t)nframes * g.nblk * 64 * sizeof(int16_t)));
+	HIPCHK(hipMalloc((void **)&enc->d_codes, (size_t)nframes * 4 * sizeof(JhHuffEnc)));
+	HIPCHK(hipMalloc((void **)&enc->d_hist, (size_t)nframes * 4 * 257 * sizeof(uint32_t)));
+	HIPCHK(hipMalloc((void **)&enc->d_wg_bits, (size_t)nframes * (w.nwg + 1) * sizeof(uint32_t)));
+	HIPCHK(hipMalloc((void **)&enc->d_us, (size_t)nframes * w.us_stride));
+	HIPCHK(hipMalloc((void **)&enc->d_chunk_ff, (size_t)nframes * w.nchunk * sizeof(uint32_t)));
+	HIPCHK(hipMalloc((void **)&enc->d_hdr_len, nframes * sizeof(uint32_t)));
+	HIPCHK(hipMalloc((void **)&enc->d_bitlen, (size_t)nframes * g.nblk * sizeof(uint16_t)));
+	HIPCHK(hipMalloc((void **)&enc->d_out, (size_t)nframes * w.out_stride));
+	HIPCHK(hipMalloc((void **)&enc->d_state, nframes * sizeof(JhEncState)));
+	w.coefs = enc->d_coefs;
+	w.codes = enc->d_codes;
+	w.hist = enc->d_hist;
+	w.bitlen = enc->d_bitlen;
+	w.wg_bits = enc->d_wg_bits;
+	w.us = enc->d_us;
+	w.chunk_ff = enc->d_chunk_ff;
+	w.out = enc->d_out;
+	w.hdr_len = enc->d_hdr_len;
+	w.state = enc->d_state;
+
+	std::vector<JhQuant> quant(nframes);
+	for (int f = 0; f < nframes; ++f) {
+		memcpy(quant[f].q, enc->Q, sizeof enc->Q);         // raster order: divisors are applied in raster order
+	}
+	HIPCHK(hipMemcpy(enc->d_quant, quant.data(), nframes * sizeof(JhQuant), hipMemcpyHostToDevice));
+	enc->headers.assign(nframes, std::vector<uint8_t>());
+	enc->hdr_len.assign(nframes, 0);
+	enc->state.assign(nframes, JhEncState());
+	// default tables + headers for every frame (the optimised path overwrites them per run)
+	return upload_codes_and_headers(enc, 0, nframes, nullptr, nullptr);
+}
+
+extern "C" int jpeg_hip_encoder_info(const jpeg_hip_encoder *enc, jpeg_hip_frame_info *info)
+{
+	if (!enc || enc->nframes == 0) {
+		return RET_FAILURE_LOGIC_ERROR;
+	}
+	fill_info(enc->g, info);
+	return RET_SUCCESS;
+}
+
+extern "C" int jpeg_hip_encoder_run(jpeg_hip_encoder *enc, const void *d_samples, size_t frame_stride, void *stream)
+{
+	if (!enc || enc->nframes == 0 || !d_samples) {
+		return RET_FAILURE_LOGIC_ERROR;
+	}
+	const JhGeom &g = enc->g;
+	if (frame_stride < (size_t)g.X * g.Y * g.Nf * g.sample_bytes) {
+		return RET_FAILURE_LOGIC_ERROR;
+	}
+	HIPCHK(hipSetDevice(enc->device));
+	hipStream_t s = (hipStream_t)stream;
+	enc->last_stream = s;
+	enc->timer.reset();
+	const JhEncodeWork &w = enc->work;
+	HIPCHK(hipMemsetAsync(enc->d_state, 0, enc->nframes * sizeof(JhEncState), s));
+	enc->timer.begin("pixels", s);
+	if (jh_launch_encode_pixels(g, enc->nframes, d_samples, frame_stride, enc->d_quant, enc->d_coefs, s)) {
+		return RET_FAILURE_LOGIC_ERROR;
+	}
+	enc->timer.end(s);
+	if (enc->prm.optimize) {
+		// write_ecs_dry() (encoder.c:525-558): histograms on the device, Annex K.2 on the host
+		// (<= 257 symbols per table, serial: SURVEY.md 8a-a18), tables back to the device.
+		enc->timer.begin("histogram", s);
+		if (jh_launch_enc_histogram(w, g, s)) {
+			return RET_FAILURE_LOGIC_ERROR;
+		}
+		enc->timer.end(s);
+		std::vector<uint32_t> hist((size_t)enc->nframes * 4 * 257);
+		HIPCHK(hipMemcpyAsync(hist.data(), enc->d_hist, hist.size() * 4, hipMemcpyDeviceToHost, s));
+		HIPCHK(hipStreamSynchronize(s));
+		std::vector<TableSet> specs(enc->nframes);
+		const int ntab = g.Nf > 1 ? 2 : 1;
+		for (int f = 0; f < enc->nframes; ++f) {
+			memcpy(specs[f].t, enc->ht, sizeof enc->ht);
+			for (int tc = 0; tc < 2; ++tc) {
+				for (int th = 0; th < ntab; ++th) {
+					uint64_t freq[257];
+					const uint32_t *h = &hist[((size_t)f * 4 + tc * 2 + th) * 257];
+					for (int i = 0; i < 256; ++i) {
+						freq[i] = h[i];
+					}
+					freq[256] = 1;                         // reserved code point (common.c:219)
+					jh_adapt_table(freq, &specs[f].t[tc][th]);
+				}
+			}
+		}
+		int err = upload_codes_and_headers(enc, 0, enc->nframes, specs.data(), s);
+		if (err) {
+			return err;
+		}
+	}
+	enc->timer.begin("entropy", s);
+	if (jh_launch_enc_entropy(w, g, s)) {
+		return RET_FAILURE_LOGIC_ERROR;
+	}
+	enc->timer.end(s);
+	enc->ran = true;
+	return RET_SUCCESS;
+}
+
+extern "C" int jpeg_hip_encoder_sync(jpeg_hip_encoder *enc, int *frame_status, size_t *jpg_len)
+{
+	if (!enc || !enc->ran) {
+		return RET_FAILURE_LOGIC_ERROR;
+	}
+	HIPCHK(hipSetDevice(enc->device));
+	HIPCHK(hipStreamSynchronize(enc->last_stream));
+	HIPCHK(hipMemcpy(enc->state.data(), enc->d_state, enc->nframes * sizeof(JhEncState), hipMemcpyDeviceToHost));
+	int worst = RET_SUCCESS;
+	for (int f = 0; f < enc->nframes; ++f) {
+		const JhEncState &st = enc->state[f];
+		int r = RET_SUCCESS;
+		if (st.status & JH_EST_DC_RANGE) {
+			r = JPEG_HIP_ERR_DC_RANGE;
+		} else if (st.status & JH_EST_NO_CODE) {
+			r = JPEG_HIP_ERR_NO_CODE;
+		} else if (st.status & JH_EST_OVERFLOW) {
+			r = RET_FAILURE_OVERFLOW_ERROR;
+		}
+		if (frame_status) {
+			frame_status[f] = r;
+		}
+		if (jpg_len) {
+			jpg_len[f] = r ? 0 : (size_t)enc->hdr_len[f] + st.ecs_bytes + 2;
+		}
+		if (r && !worst) {
+			worst = r;
+		}
+	}
+	return worst;
+}
+
+extern "C" int jpeg_hip_encoder_get_jpeg(jpeg_hip_encoder *enc, int frame, uint8_t *out, size_t cap, size_t *len)
+{
+	if (!enc || !enc->ran || frame < 0 || frame >= enc->nframes) {
+		return RET_FAILURE_LOGIC_ERROR;
+	}
+	const size_t n = (size_t)enc->hdr_len[frame] + enc->state[frame].ecs_bytes + 2;
+	*len = n;
+	if (cap < n) {
+		return RET_FAILURE_OVERFLOW_ERROR;
+	}
+	HIPCHK(hipSetDevice(enc->device));
+	HIPCHK(hipMemcpy(out, enc->d_out + (size_t)frame * enc->work.out_stride, n, hipMemcpyDeviceToHost));
+	return RET_SUCCESS;
+}
+
+extern "C" const void *jpeg_hip_encoder_device_jpeg(jpeg_hip_encoder *enc, int frame, size_t *len)
+{
+	if (!enc || !enc->ran || frame < 0 || frame >= enc->nframes) {
+		return nullptr;
+	}
+	*len = (size_t)enc->hdr_len[frame] + enc->state[frame].ecs_bytes + 2;
+	return enc->d_out + (size_t)frame * enc->work.out_stride;
+}
+
+extern "C" int jpeg_hip_encoder_get_coefficients(jpeg_hip_encoder *enc, int frame, int k, int32_t *out)
+{
+	if (!enc || !enc->ran || frame < 0 || frame >= enc->nframes || k < 0 || k >= enc->g.ncomp) {
+		return RET_FAILURE_LOGIC_ERROR;
+	}
+	HIPCHK(hipSetDevice(enc->device));
+	const size_t n = (size_t)enc->g.nblk * 64;
+	std::vector<int16_t> fc(n);
+	HIPCHK(hipMemcpy(fc.data(), enc->d_coefs + (size_t)frame * n, n * sizeof(int16_t), hipMemcpyDeviceToHost));
+	coefs_to_reference_layout(enc->g, fc.data(), k, out);
+	return RET_SUCCESS;
+}
+
+extern "C" void jpeg_hip_encoder_set_timing(jpeg_hip_encoder *enc, int on) { enc->timer.on = on != 0; }
+
+extern "C" int jpeg_hip_encoder_get_timing(jpeg_hip_encoder *enc, const char **names, float *ms, int cap)
+{
+	hipSetDevice(enc->device);
+	return enc->timer.collect(names, ms, cap);
+}
+
+// ======================================================================================= single-image drop-ins
+
+static int slurp(FILE *f, std::vector<uint8_t> *out)
+{
+	uint8_t buf[65536];
+	size_t n;
+	while ((n = fread(buf, 1, sizeof buf, f)) > 0) {
+		out->insert(out->end(), buf, buf + n);
+	}
+	return ferror(f) ? RET_FAILURE_FILE_IO : RET_SUCCESS;
+}
+
+// decoder.c:661-685 process_jpeg_stream: one SOI..EOI codestream -> PPM/PGM at `path`
+extern "C" int jpeg_hip_process_jpeg_stream(FILE *stream, const char *path)
+{
+	std::vector<uint8_t> data;
+	int err = slurp(stream, &data);
+	if (err) {
+		return err;
+	}
+	jpeg_hip_decoder *dec = nullptr;
+	err = jpeg_hip_decoder_create(&dec, 0);
+	if (err) {
+		fprintf(stderr, "malloc failure\n");
+		return err;
+	}
+	const uint8_t *p = data.data();
+	size_t n = data.size();
+	void *d_out = nullptr;
+	std::vector<uint8_t> body;
+	jpeg_hip_frame_info fi;
+	err = jpeg_hip_decoder_prepare(dec, 1, &p, &n);
+	if (!err) {
+		jpeg_hip_decoder_info(dec, &fi);
+		const size_t fb = jpeg_hip_decoder_frame_bytes(dec);
+		if (hipMalloc(&d_out, fb ? fb : 1) != hipSuccess) {
+			err = RET_FAILURE_MEMORY_ALLOCATION;
+		}
+		if (!err) {
+			err = jpeg_hip_decoder_run(dec, d_out, fb, nullptr);
+		}
+		int st = 0;
+		if (!err) {
+			err = jpeg_hip_decoder_sync(dec, &st);
+		}
+		if (!err) {
+			body.resize(fb);
+			if (hipMemcpy(body.data(), d_out, fb, hipMemcpyDeviceToHost) != hipSuccess) {
+				err = RET_FAILURE_LOGIC_ERROR;
+			}
+		}
+	}
+	if (!err) {
+		// write_frame (frame.c:548-567) + write_frame_header (:407-429)
+		const bool gray = fi.out_components == 1;
+		FILE *o = fopen(path ? path : (gray ? "output.pgm" : "output.ppm"), "w");
+		if (!o) {
+			err = RET_FAILURE_FILE_OPEN;
+		} else {
+			if (fprintf(o, "%s\n%u %u\n%i\n", gray ? "P5" : "P6", (unsigned)fi.X, (unsigned)fi.Y, (1 << fi.P) - 1) < 0 ||
+			    fwrite(body.data(), 1, body.size(), o) < body.size()) {
+				err = RET_FAILURE_FILE_IO;
+			}
+			fclose(o);
+		}
+	}
+	if (d_out) {
+		hipFree(d_out);
+	}
+	jpeg_hip_decoder_destroy(dec);
+	return err;
+}
+
+// decoder.c:687-701
+extern "C" int jpeg_hip_process_jpeg_file(const char *i_path, const char *o_path)
+{
+	FILE *stream = fopen(i_path, "r");
+	if (stream == NULL) {
+		fprintf(stderr, "fopen failure\n");
+		return RET_FAILURE_FILE_OPEN;
+	}
+	int err = jpeg_hip_process_jpeg_stream(stream, o_path);
+	fclose(stream);
+	return err;
+}
+
+// frame.c:431-522 read_frame_header restated on a byte buffer
+static int parse_pnm_header(const std::vector<uint8_t> &d, size_t *pos, int *comps, int *X, int *Y, int *P)
+{
+	size_t i = 0;
+	auto skip_ws = [&]() { while (i < d.size() && isspace(d[i])) ++i; };
+	auto skip_comments = [&]() {
+		while (i < d.size() && d[i] == '#') {
+			while (i < d.size() && d[i] != '\n') ++i;
+			if (i < d.size()) ++i;
+		}
+	};
+	auto number = [&](long *v) -> bool {
+		skip_ws();
+		if (i >= d.size() || !isdigit(d[i])) return false;
+		long r = 0;
+		while (i < d.size() && isdigit(d[i])) { r = r * 10 + (d[i] - '0'); if (r > 1000000) return false; ++i; }
+		*v = r;
+		return true;
+	};
+	if (d.size() < 2) return RET_FAILURE_FILE_IO;
+	if (d[0] != 'P') return RET_FAILURE_FILE_UNSUPPORTED;
+	if (d[1] == '5') *comps = 1; else if (d[1] == '6') *comps = 3; else return RET_FAILURE_FILE_UNSUPPORTED;
+	i = 2;
+	skip_ws();
+	skip_comments();
+	long w, h, maxval;
+	if (!number(&w)) return RET_FAILURE_FILE_IO;
+	skip_ws();
+	skip_comments();
+	if (!number(&h)) return RET_FAILURE_FILE_IO;
+	skip_ws();
+	skip_comments();
+	if (!number(&maxval) || maxval <= 0) return RET_FAILURE_FILE_IO;
+	int prec = 0;
+	for (long m = maxval; m; m >>= 1) ++prec;              // floor_log2 + 1 (frame.c:259-275)
+	if (prec > 16) return RET_FAILURE_FILE_UNSUPPORTED;
+	skip_comments();
+	if (i >= d.size() || !isspace(d[i])) return RET_FAILURE_FILE_UNSUPPORTED;
+	++i;
+	if (w <= 0 || h <= 0 || w > 65535 || h > 65535) return RET_FAILURE_FILE_UNSUPPORTED;
+	*X = (int)w; *Y = (int)h; *P = prec; *pos = i;
+	return RET_SUCCESS;
+}
+
+// encoder.c:647-667 process_stream: PPM/PGM in, JPEG out
+extern "C" int jpeg_hip_process_stream(FILE *i_stream, FILE *o_stream, const jpeg_hip_params *params)
+{
+	std::vector<uint8_t> data;
+	int err = slurp(i_stream, &data);
+	if (err) {
+		return err;
+	}
+	size_t pos = 0;
+	int comps, X, Y, P;
+	err = parse_pnm_header(data, &pos, &comps, &X, &Y, &P);
+	if (err) {
+		return err;
+	}
+	const size_t ss = P <= 8 ? 1 : 2;
+	const size_t body = (size_t)X * Y * comps * ss;
+	if (data.size() - pos < body) {
+		return RET_FAILURE_FILE_IO;                        // frame.c:296-299
+	}
+	if (P > 12) {
+		return RET_FAILURE_FILE_UNSUPPORTED;               // int16 coefficient storage: P <= 12
+	}
+	jpeg_hip_encoder *enc = nullptr;
+	err = jpeg_hip_encoder_create(&enc, 0);
+	if (err) {
+		return err;
+	}
+	void *d_in = nullptr;
+	std::vector<uint8_t> jpg;
+	err = jpeg_hip_encoder_configure(enc, 1, X, Y, comps, P, params);
+	if (!err && hipMalloc(&d_in, body ? body : 1) != hipSuccess) {
+		err = RET_FAILURE_MEMORY_ALLOCATION;
+	}
+	if (!err && hipMemcpy(d_in, data.data() + pos, body, hipMemcpyHostToDevice) != hipSuccess) {
+		err = RET_FAILURE_LOGIC_ERROR;
+	}
+	if (!err) {
+		err = jpeg_hip_encoder_run(enc, d_in, body, nullptr);
+	}
+	size_t len = 0;
+	int st = 0;
+	if (!err) {
+		err = jpeg_hip_encoder_sync(enc, &st, &len);
+	}
+	if (!err) {
+		jpg.resize(len);
+		err = jpeg_hip_encoder_get_jpeg(enc, 0, jpg.data(), jpg.size(), &len);
+	}
+	if (!err && fwrite(jpg.data(), 1, len, o_stream) < len) {
+		err = RET_FAILURE_FILE_IO;
+	}
+	if (d_in) {
+		hipFree(d_in);
+	}
+	jpeg_hip_encoder_destroy(enc);
+	return err;
+}

@@ -1,0 +1,41 @@
+// jpeg_amd/csrc/codestream.hpp -- host-side codestream layer (markers, tables, geometry).
+// Serial, byte-sized work that stays on the CPU; it feeds the
+// device kernels with geometry and <= 10 KB of tables per frame.
+#pragma once
+
+#include <vector>
+#include <stdint.h>
+#include <stddef.h>
+#include "common.hpp"
+
+struct JhHuffSpec {                   // DHT payload (common.h:85-91), flattened
+	uint8_t L[16];
+	uint8_t V[256];
+};
+
+struct JhHeader {
+	JhGeom g;
+	uint16_t Q[4][64];                // raster order, as the reference stores it (common.h:52-57)
+	JhHuffSpec ht[2][4];              // [Tc][Th]; starts as the implicit MJPEG tables (common.c:90-99)
+	int Ns;
+	int scan_comp[JH_MAX_COMP];       // index into g.* of each scan component
+	size_t ecs_offset;                // first byte after the SOS header
+};
+
+// Parse SOI .. SOS of one codestream held in memory (decoder.c:472-659 restated).  Returns a RET_* code.
+int jh_parse_headers(const uint8_t *p, size_t n, JhHeader *h);
+
+// Geometry from P/X/Y/components (common.c:156-195, frame.c:16-35).  interleaved = scan holds all
+// components; a single-component frame is normalised to H = V = 1 over its padded block grid
+// (the reference's Ns == 1 walk, decoder.c:274-302).
+int jh_finish_geometry(JhGeom *g);
+
+void jh_default_table(int Tc, int Th, JhHuffSpec *s);                 // mjpeg.h:5-82
+void jh_set_qtable(uint16_t Q[64], int chroma, int q);                // encoder.c:14-65
+int  jh_build_declut(const JhHuffSpec *s, JhHuffLut *lut);            // huffman.c:45-148 -> decode tables
+int  jh_build_enccodes(const JhHuffSpec *s, JhHuffEnc *e);            // huffman.c:228-253 first-match codes
+void jh_adapt_table(const uint64_t freq[257], JhHuffSpec *s);         // huffman.c:330-537 (Annex K.2)
+
+// SOI, DQT.., SOF0, DHT.., [DRI], SOS  (encoder.c:195-400, order of produce_codestream :589-645)
+void jh_produce_headers(const JhGeom &g, const uint16_t Q[4][64], const JhHuffSpec ht[2][4],
+                        int restart_interval, std::vector<uint8_t> *out);

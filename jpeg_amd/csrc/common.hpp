@@ -1,0 +1,96 @@
+// jpeg_amd/csrc/common.hpp -- shared definitions of the HIP codec core (host + device).
+//
+// Data model restated from the reference (common.h:52-156, coeffs.h:9-16) for the GPU:
+//   * coefficients live in HBM as int16, in SCAN ORDER: block index = mcu * B + k, where k walks the
+//     blocks of one MCU the way read_macroblock()/write_macroblock() do (component, v, h;
+//     decoder.c:319-357, encoder.c:425-461), and in ZIG-ZAG order inside a block (one 128-byte
+//     line per block).  The reference keeps int32, per component, raster order (a1 in SURVEY 8a);
+//     the taps in api.hip convert back for parity tests.
+//   * one batch = frames that share geometry (Motion JPEG); tables are per frame.
+#pragma once
+
+#include <stdint.h>
+#include <stddef.h>
+
+#define JH_MAX_COMP 4
+#define JH_MAX_MCU_BLOCKS 10          // JPEG limit on sum(H*V) in an interleaved scan
+
+// ---- Huffman decode look-up ---------------------------------------------------------------
+#define JH_LUT_BITS 10                // fast table index width
+#define JH_SUBSEQ_BITS 1024           // bits per speculative sub-sequence (one thread each)
+#define JH_SUBSEQ_BYTES (JH_SUBSEQ_BITS / 8)
+#define JH_SYNC_ITERS 3               // inter-sequence synchronisation launches per run
+
+struct JhHuffLut {                    // one Huffman table, decoder view (Annex C / F.2.2.3)
+	uint16_t fast[1 << JH_LUT_BITS];  // (len << 8) | symbol for codes <= JH_LUT_BITS bits, else 0
+	uint32_t limit[17];               // limit[l] = (maxcode[l] + 1) << (16 - l), non-decreasing; l = 1..16
+	int32_t  offs[17];                // valptr[l] - mincode[l]
+	uint8_t  huffval[256];
+};
+
+struct JhHuffEnc {                    // one Huffman table, encoder view (EHUFCO/EHUFSI, huffman.c:118-148)
+	uint32_t code[256];               // (code << 8) | size ; size == 0: symbol absent
+};
+
+// ---- geometry -------------------------------------------------------------------------------
+struct JhGeom {
+	int P, X, Y, Nf;
+	int ncomp;
+	int id[JH_MAX_COMP], H[JH_MAX_COMP], V[JH_MAX_COMP];
+	int Tq[JH_MAX_COMP], Td[JH_MAX_COMP], Ta[JH_MAX_COMP];
+	int scan_order[JH_MAX_COMP];      // component (index into id/H/V..) of the j-th scan component
+	int max_H, max_V;
+	int m_x, m_y;
+	int size_x, size_y;
+	int bx[JH_MAX_COMP], by[JH_MAX_COMP];
+	int B;                            // blocks per MCU in scan order
+	int nmcu;                         // m_x * m_y
+	int nblk;                         // nmcu * B
+	int blk_comp[JH_MAX_MCU_BLOCKS];  // component of block k of an MCU
+	int blk_h[JH_MAX_MCU_BLOCKS], blk_v[JH_MAX_MCU_BLOCKS];
+	int comp_first[JH_MAX_COMP];      // first block of the component inside an MCU
+	int step_x[JH_MAX_COMP], step_y[JH_MAX_COMP];   // frame.c:57-58 replication / box factors
+	int out_comps;                    // 1 or 3
+	int sample_bytes;                 // 1 or 2
+	int Ri;
+};
+
+// per-frame quantisation tables as the kernels want them: [table][zig-zag position]
+struct JhQuant {
+	uint16_t q[4][64];
+};
+
+// ---- speculative Huffman decoder records ---------------------------------------------------
+// Exit state of a sub-sequence: where the first symbol NOT belonging to it starts, and the
+// position inside the MCU / block.  Packed in one 64-bit word so that it is read/written atomically.
+//   bits  0..31 pos (bit offset in the frame's unstuffed stream)
+//   bits 32..39 c   (block inside the MCU)
+//   bits 40..47 z   (next zig-zag index, 0 = DC expected)
+//   bit  48     reset seen inside the sub-sequence (restart boundary crossed)
+struct JhSubInfo {
+	unsigned long long state;
+	uint32_t seg;                     // restart segment index at the exit position
+	int32_t  nb;                      // blocks completed (MCU-rounded at restart boundaries)
+	int32_t  dc[JH_MAX_COMP];         // sum of DC differences per component since the last reset
+};
+
+struct JhSubStart {                   // entry of a sub-sequence for the write pass (after the scan)
+	unsigned long long state;
+	uint32_t seg;
+	int32_t  blk;                     // index of the block in progress
+	int32_t  pred[JH_MAX_COMP];       // DC predictors
+};
+
+#ifdef __HIPCC__
+#define JH_HD __host__ __device__
+#else
+#define JH_HD
+#endif
+
+// zig-zag position -> raster index (common.h:34-43)
+static const uint8_t jh_zigzag[64] = {
+	 0,  1,  8, 16,  9,  2,  3, 10, 17, 24, 32, 25, 18, 11,  4,  5,
+	12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13,  6,  7, 14, 21, 28,
+	35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51,
+	58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63
+};

@@ -1,0 +1,819 @@
+// jpeg_amd/csrc/huffdec.hip -- entropy DEcoding on gfx950.
+//
+// Replaces the reference's bit-serial loop
+//     read_ecs (decoder.c:364-388) -> read_macroblock (:262-362) -> read_block (coeffs.c:196-254)
+//       -> read_code (huffman.c:255-271: one next_bit() + one linear query_code() per bit)
+//       -> read_extra_bits (huffman.c:294-312) -> decode_coeff (coeffs.c:33-48)
+// which is >90 % of the reference's decode time, by a data-parallel scheme:
+//
+//   1. k_ecs_scan / k_ecs_chunk_scan / k_ecs_compact
+//        byte un-stuffing (FF 00 -> FF, io.c:257-264) and RSTn segmentation (decoder.c:622-633) as
+//        count -> scan -> scatter.  Output: one contiguous unstuffed bit stream per frame plus the
+//        byte offset at which every restart segment starts.  The ECS ends at the first FF xx with
+//        xx not in {00, D0..D7} (io.c:265-269).
+//   2. k_huff_sync_intra
+//        the stream is cut into sub-sequences of JH_SUBSEQ_BITS bits, one thread each.  Every thread
+//        decodes its sub-sequence from the guess "a DC code of block 0 starts at my first bit" and
+//        records its exit state (bit position, block-in-MCU, zig-zag index).  Huffman streams
+//        self-synchronise: a wrong guess falls into step with the true parse after a few symbols.
+//        Threads then keep decoding into the following sub-sequences and overwrite the stored exit
+//        states until their own state equals the stored one (earlier-starting chains win; the first
+//        sub-sequence of a frame, and everything after a restart boundary, is known to be right).
+//   3. k_huff_sync_inter   the same across workgroup boundaries, iterated to a fixed point
+//   4. k_huff_scan         exclusive (restart-segmented) prefix sums of blocks and DC differences
+//   5. k_huff_write        every thread re-decodes its sub-sequence from its now-known entry state
+//                          and scatters coefficients (absolute DC) into the int16 scan-order buffer.
+//
+// A restart boundary inside a sub-sequence resets the state (c = z = 0, predictors 0) whatever the
+// state before was, so restart intervals and speculative decoding are ONE mechanism here: with
+// markers every chain synchronises at the next marker at the latest; without them by self-synchronisation.
+// The reference ignores Ri (quirk Q1); so does this code: segments are delimited by the markers found.
+//
+// Exactness: integer work; every symbol is decoded exactly as F.2.2 prescribes (canonical codes,
+// first match = shortest match), so coefficients are bit-identical to the reference's.
+#include <hip/hip_runtime.h>
+#include "common.hpp"
+#include "kernels.hpp"
+
+#define CHUNK_BYTES 4096              // raw bytes per workgroup in the un-stuffing kernels (256 x 16)
+
+// ===================================================================================== 1. un-stuffing
+
+// classification of one raw byte
+//   bit0 kept (payload)   bit1 RSTn lead (FF of FF Dn)   bit2 terminator lead (FF xx, xx not 00/Dn)
+__device__ __forceinline__ unsigned classify(unsigned prev, unsigned b, unsigned next)
+{
+	if (b == 0xffu) {
+		if (next == 0x00u) {
+			return 1u;                 // stuffed FF: data
+		}
+		if ((next & 0xf8u) == 0xd0u) {
+			return 2u;                 // RSTn
+		}
+		return 4u;                     // any other marker (or fill byte): end of the entropy-coded data
+	}
+	if (prev == 0xffu && (b == 0x00u || (b & 0xf8u) == 0xd0u)) {
+		return 0u;                     // stuffed zero / second byte of RSTn
+	}
+	return 1u;
+}
+
+struct RawWindow {
+	unsigned bytes[18];               // [0] = byte before, [1..16] = own, [17] = byte after
+};
+
+// thread `tid` of chunk `chunk` owns absolute bytes [base, base + 16)
+__device__ __forceinline__ void load_window(const uint8_t *raw, uint32_t lo, uint32_t hi, uint32_t base, RawWindow &w)
+{
+	// 16-byte aligned vector load where the whole window is inside the frame, byte loads at the edges
+	if (base >= lo && base + 16 <= hi) {
+		const uint4 v = *reinterpret_cast<const uint4 *>(raw + base);
+		const unsigned ws[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+		for (int i = 0; i < 16; ++i) {
+			w.bytes[1 + i] = (ws[i >> 2] >> (8 * (i & 3))) & 0xffu;
+		}
+	} else {
+#pragma unroll
+		for (int i = 0; i < 16; ++i) {
+			const uint32_t p = base + i;
+			w.bytes[1 + i] = (p >= lo && p < hi) ? raw[p] : (p >= hi ? 0xd9u : 0u);
+		}
+	}
+	w.bytes[0] = (base > lo && base - 1 < hi) ? raw[base - 1] : 0u;
+	// a frame that ends in a lone FF: treat the missing byte as a marker code
+	w.bytes[17] = (base + 16 < hi) ? raw[base + 16] : 0xd9u;
+}
+
+__device__ __forceinline__ unsigned block_reduce_add(unsigned v, unsigned *scratch)
+{
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) {
+		v += __shfl_down(v, o, 64);
+	}
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	if (lane == 0) {
+		scratch[wv] = v;
+	}
+	__syncthreads();
+	unsigned r = scratch[0] + scratch[1] + scratch[2] + scratch[3];
+	__syncthreads();
+	return r;
+}
+
+// exclusive prefix over the 256 threads of the block; total returned through *total
+__device__ __forceinline__ unsigned block_excl_scan(unsigned v, unsigned *scratch, unsigned *total)
+{
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	unsigned inc = v;
+#pragma unroll
+	for (int o = 1; o < 64; o <<= 1) {
+		unsigned t = __shfl_up(inc, o, 64);
+		if (lane >= o) {
+			inc += t;
+		}
+	}
+	if (lane == 63) {
+		scratch[wv] = inc;
+	}
+	__syncthreads();
+	unsigned base = 0;
+	for (int i = 0; i < wv; ++i) {
+		base += scratch[i];
+	}
+	*total = scratch[0] + scratch[1] + scratch[2] + scratch[3];
+	__syncthreads();
+	return base + inc - v;
+}
+
+__global__ __launch_bounds__(256) void k_ecs_scan(JhDecodeWork w)
+{
+	__shared__ unsigned scratch[4];
+	const int f = blockIdx.y;
+	const JhDecFrame fr = w.frames[f];
+	if (blockIdx.x >= fr.nchunk) {
+		return;
+	}
+	// chunks are aligned to absolute multiples of CHUNK_BYTES so that vector loads are aligned
+	const uint32_t base = (fr.raw_begin / CHUNK_BYTES + blockIdx.x) * CHUNK_BYTES + threadIdx.x * 16;
+	RawWindow win;
+	load_window(w.raw, fr.raw_begin, fr.raw_end, base, win);
+	unsigned kept = 0, rst = 0;
+	uint32_t term = 0xffffffffu;
+#pragma unroll
+	for (int i = 0; i < 16; ++i) {
+		const uint32_t p = base + i;
+		if (p >= fr.raw_begin && p < fr.raw_end) {
+			const unsigned cl = classify(win.bytes[i], win.bytes[i + 1], win.bytes[i + 2]);
+			kept += cl & 1u;
+			rst += (cl >> 1) & 1u;
+			if ((cl & 4u) && term == 0xffffffffu) {
+				term = p;
+			}
+		}
+	}
+	if (term != 0xffffffffu) {
+		atomicMin(&w.state[f].term_pos, term);
+	}
+	const unsigned tk = block_reduce_add(kept, scratch);
+	const unsigned tr = block_reduce_add(rst, scratch);
+	if (threadIdx.x == 0) {
+		w.chunk_kept[fr.chunk_off + blockIdx.x] = tk;
+		w.chunk_rst[fr.chunk_off + blockIdx.x] = tr;
+	}
+}
+
+// one workgroup per frame: exclusive scan of the per-chunk counts (in place)
+__global__ __launch_bounds__(256) void k_ecs_chunk_scan(JhDecodeWork w)
+{
+	__shared__ unsigned scratch[4];
+	const int f = blockIdx.x;
+	const JhDecFrame fr = w.frames[f];
+	unsigned carry_k = 0, carry_r = 0;
+	for (uint32_t c0 = 0; c0 < fr.nchunk; c0 += 256) {
+		const uint32_t c = c0 + threadIdx.x;
+		const unsigned k = c < fr.nchunk ? w.chunk_kept[fr.chunk_off + c] : 0u;
+		const unsigned r = c < fr.nchunk ? w.chunk_rst[fr.chunk_off + c] : 0u;
+		unsigned tk, tr;
+		const unsigned ek = block_excl_scan(k, scratch, &tk);
+		const unsigned er = block_excl_scan(r, scratch, &tr);
+		if (c < fr.nchunk) {
+			w.chunk_kept[fr.chunk_off + c] = carry_k + ek;
+			w.chunk_rst[fr.chunk_off + c] = carry_r + er;
+		}
+		carry_k += tk;
+		carry_r += tr;
+	}
+	if (threadIdx.x == 0) {
+		JhDecState &st = w.state[f];
+		// totals for a stream without terminating marker; k_ecs_compact overrides them otherwise
+		if (st.term_pos > fr.raw_end) {
+			st.term_pos = fr.raw_end;
+		}
+		st.cs_len = carry_k;
+		st.nseg = carry_r + 1;
+		w.seg_start[fr.seg_off] = 0;
+		if (carry_r + 1 < fr.seg_cap) {
+			w.seg_start[fr.seg_off + carry_r + 1] = carry_k;
+		}
+	}
+}
+
+__global__ __launch_bounds__(256) void k_ecs_compact(JhDecodeWork w)
+{
+	__shared__ unsigned scratch[4];
+	const int f = blockIdx.y;
+	const JhDecFrame fr = w.frames[f];
+	if (blockIdx.x >= fr.nchunk) {
+		return;
+	}
+	JhDecState &st = w.state[f];
+	const uint32_t term = st.term_pos;
+	const uint32_t base = (fr.raw_begin / CHUNK_BYTES + blockIdx.x) * CHUNK_BYTES + threadIdx.x * 16;
+	RawWindow win;
+	load_window(w.raw, fr.raw_begin, fr.raw_end, base, win);
+	unsigned cls[16];
+	unsigned kept = 0, rst = 0;
+#pragma unroll
+	for (int i = 0; i < 16; ++i) {
+		const uint32_t p = base + i;
+		cls[i] = (p >= fr.raw_begin && p < fr.raw_end) ? classify(win.bytes[i], win.bytes[i + 1], win.bytes[i + 2]) : 0u;
+		kept += cls[i] & 1u;
+		rst += (cls[i] >> 1) & 1u;
+	}
+	unsigned tk, tr;
+	unsigned ok = w.chunk_kept[fr.chunk_off + blockIdx.x] + block_excl_scan(kept, scratch, &tk);
+	unsigned orr = w.chunk_rst[fr.chunk_off + blockIdx.x] + block_excl_scan(rst, scratch, &tr);
+	uint8_t *cs = w.cs + fr.cs_off;
+#pragma unroll
+	for (int i = 0; i < 16; ++i) {
+		const uint32_t p = base + i;
+		if (p == term && p < fr.raw_end) {
+			// the marker that ends the entropy-coded data: everything before it has been counted
+			st.term_marker = win.bytes[i + 2];
+			st.cs_len = ok;
+			st.nseg = orr + 1;
+			if (orr + 1 < fr.seg_cap) {
+				w.seg_start[fr.seg_off + orr + 1] = ok;
+			} else {
+				atomicOr(&st.status, JH_ST_SEG_OVERFLOW);
+			}
+		}
+		if (p < term) {
+			if (cls[i] & 1u) {
+				cs[ok] = (uint8_t)win.bytes[i + 1];
+			}
+			if (cls[i] & 2u) {
+				// segment (orr + 1) starts at the payload byte that follows this marker
+				if (orr + 1 < fr.seg_cap) {
+					w.seg_start[fr.seg_off + orr + 1] = ok;
+				} else {
+					atomicOr(&st.status, JH_ST_SEG_OVERFLOW);
+				}
+			}
+		}
+		ok += cls[i] & 1u;
+		orr += (cls[i] >> 1) & 1u;
+	}
+}
+
+int jh_launch_ecs_unstuff(const JhDecodeWork &w, hipStream_t s)
+{
+	dim3 grid(w.max_chunks, w.nframes);
+	hipLaunchKernelGGL(k_ecs_scan, grid, dim3(256), 0, s, w);
+	hipLaunchKernelGGL(k_ecs_chunk_scan, dim3(w.nframes), dim3(256), 0, s, w);
+	hipLaunchKernelGGL(k_ecs_compact, grid, dim3(256), 0, s, w);
+	return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// ===================================================================================== 2. decoding core
+
+struct DecTables {                    // workgroup-shared decode context (LDS)
+	uint8_t blk_dc[JH_MAX_MCU_BLOCKS], blk_ac[JH_MAX_MCU_BLOCKS], blk_comp[JH_MAX_MCU_BLOCKS];
+	uint8_t pad[2];
+};
+
+struct DecState {
+	uint32_t pos;                     // bit position of the next symbol
+	uint32_t seg;                     // restart segment that contains pos
+	int c, z;                         // block inside the MCU, next zig-zag index (0 = DC expected)
+	int reset;                        // a restart boundary was crossed
+	int nb;                           // blocks completed (partial MCUs before a boundary are discarded)
+	int dc[JH_MAX_COMP];              // DC difference sums since the last reset (WRITE: the predictors)
+};
+
+__device__ __forceinline__ unsigned long long pack_state(const DecState &s)
+{
+	return (unsigned long long)s.pos | ((unsigned long long)(s.c & 0xff) << 32) |
+	       ((unsigned long long)(s.z & 0xff) << 40) | ((unsigned long long)(s.reset & 1) << 48);
+}
+
+__device__ __forceinline__ uint32_t load_be32(const uint8_t *cs, uint32_t word)
+{
+	return __builtin_bswap32(reinterpret_cast<const uint32_t *>(cs)[word]);
+}
+
+// F.12: extend the sign of a cat-bit magnitude field (coeffs.c:33-48)
+__device__ __forceinline__ int extend(unsigned extra, int cat)
+{
+	return cat == 0 ? 0 : ((extra >> (cat - 1)) ? (int)extra : (int)extra - (1 << cat) + 1);
+}
+
+// Decode every symbol that STARTS before bit `stop`, beginning at st.pos.  WRITE selects the final
+// pass (coefficients stored, st.dc = predictors, blk = index of the block in progress).
+template <bool WRITE>
+__device__ __forceinline__ void decode_span(DecState &st, const uint32_t stop, const uint8_t *cs,
+                                            const uint32_t total_bits, const uint32_t *seg_start,
+                                            const uint32_t nseg, const JhHuffLut *luts,
+                                            const DecTables &tb, const int B,
+                                            int16_t *coefs, int blk, const int nblk)
+{
+	if (st.pos >= stop || st.pos >= total_bits) {
+		return;
+	}
+	uint32_t seg_end = min(seg_start[st.seg + 1] * 8u, total_bits);
+	uint32_t wpos = st.pos >> 5;
+	unsigned long long buf = ((unsigned long long)load_be32(cs, wpos) << 32) | load_be32(cs, wpos + 1);
+	buf <<= (st.pos & 31u);
+	int avail = 64 - (int)(st.pos & 31u);
+	wpos += 2;
+	uint32_t pos = st.pos;
+	int c = st.c, z = st.z;
+
+	while (pos < stop) {
+		if (avail < 32) {
+			buf |= (unsigned long long)load_be32(cs, wpos++) << (32 - avail);
+			avail += 32;
+		}
+		const JhHuffLut &lut = luts[z == 0 ? tb.blk_dc[c] : tb.blk_ac[c]];
+		unsigned e = lut.fast[(unsigned)(buf >> (64 - JH_LUT_BITS))];
+		int len = (int)(e >> 8);
+		unsigned sym = e & 0xffu;
+		bool invalid = false;
+		if (len == 0) {
+			// code longer than the fast table: canonical search on the left-aligned 16-bit window
+			const unsigned v = (unsigned)(buf >> 48);
+			len = JH_LUT_BITS + 1;
+#pragma unroll
+			for (int l = JH_LUT_BITS + 1; l < 16; ++l) {
+				len += v >= lut.limit[l] ? 1 : 0;
+			}
+			if (v >= lut.limit[16]) {
+				invalid = true;       // no code matches: the reference reads on to the end of the segment
+				sym = 0;
+			} else {
+				sym = lut.huffval[(lut.offs[len] + (int)(v >> (16 - len))) & 0xff];
+			}
+		}
+		const int cat = (int)(sym & 15u);
+		const int total = len + cat;
+		if (invalid || pos + (uint32_t)total > seg_end) {
+			// end of this restart segment (padding bits, truncated data or garbage): decoder.c:376-381.
+			// The MCU in progress is dropped (context->mblocks is not incremented), the next segment
+			// starts with block 0 / DC predictors 0 (decoder.c:369-373).
+			st.nb -= c;
+			if (WRITE) {
+				blk -= c;
+			}
+			c = 0;
+			z = 0;
+			st.reset = 1;
+#pragma unroll
+			for (int k = 0; k < JH_MAX_COMP; ++k) {
+				st.dc[k] = 0;
+			}
+			st.seg++;
+			if (st.seg >= nseg) {
+				pos = total_bits;
+				break;
+			}
+			pos = seg_end;
+			seg_end = min(seg_start[st.seg + 1] * 8u, total_bits);
+			wpos = pos >> 5;
+			buf = ((unsigned long long)load_be32(cs, wpos) << 32) | load_be32(cs, wpos + 1);
+			buf <<= (pos & 31u);
+			avail = 64 - (int)(pos & 31u);
+			wpos += 2;
+			continue;
+		}
+		const unsigned extra = cat ? (unsigned)((buf << len) >> (64 - cat)) : 0u;
+		buf <<= total;
+		avail -= total;
+		pos += (uint32_t)total;
+		if (z == 0) {
+			const int diff = extend(extra, cat);
+			const int comp = tb.blk_comp[c];
+			// dynamic index into a tiny array: keep it in registers with a select chain
+			int val = 0;
+#pragma unroll
+			for (int k = 0; k < JH_MAX_COMP; ++k) {
+				if (k == comp) {
+					st.dc[k] += diff;
+					val = st.dc[k];
+				}
+			}
+			if (WRITE && blk >= 0 && blk < nblk) {
+				coefs[(size_t)blk * 64] = (int16_t)val;      // DC un-prediction (decoder.c:351-355)
+			}
+			z = 1;
+		} else if (sym == 0) {
+			z = 64;                                            // EOB (coeffs.c:241-243)
+		} else {
+			z += (int)(sym >> 4);                              // zero run (coeffs.c:246)
+			if (WRITE && cat != 0 && z < 64 && blk >= 0 && blk < nblk) {
+				coefs[(size_t)blk * 64 + z] = (int16_t)extend(extra, cat);
+			}
+			z++;
+		}
+		if (z >= 64) {
+			z = 0;
+			c = (c + 1 == B) ? 0 : c + 1;
+			st.nb++;
+			if (WRITE) {
+				blk++;
+			}
+		}
+	}
+	st.pos = pos;
+	st.c = c;
+	st.z = z;
+}
+
+// segment that contains byte offset `byte` : largest k with seg_start[k] <= byte
+__device__ __forceinline__ uint32_t find_segment(const uint32_t *seg_start, uint32_t nseg, uint32_t byte)
+{
+	uint32_t lo = 0, hi = nseg;   // invariant: seg_start[lo] <= byte, answer in [lo, hi)
+	while (hi - lo > 1) {
+		const uint32_t mid = (lo + hi) >> 1;
+		if (seg_start[mid] <= byte) {
+			lo = mid;
+		} else {
+			hi = mid;
+		}
+	}
+	return lo;
+}
+
+__device__ __forceinline__ void load_tables(const JhDecodeWork &w, const JhDecFrame &fr, JhHuffLut *luts, DecTables *tb,
+                                            const JhGeom &g)
+{
+	const uint32_t *src = reinterpret_cast<const uint32_t *>(w.luts + fr.lut_off);
+	uint32_t *dst = reinterpret_cast<uint32_t *>(luts);
+	const int nw = (int)(fr.n_lut * sizeof(JhHuffLut) / 4);
+	for (int i = threadIdx.x; i < nw; i += blockDim.x) {
+		dst[i] = src[i];
+	}
+	if (threadIdx.x < JH_MAX_MCU_BLOCKS) {
+		// read through the global pointer: indexing the by-value copy would put it in scratch
+		const JhDecFrame *gf = w.frames + blockIdx.y;
+		tb->blk_dc[threadIdx.x] = gf->blk_dc[threadIdx.x];
+		tb->blk_ac[threadIdx.x] = gf->blk_ac[threadIdx.x];
+		tb->blk_comp[threadIdx.x] = (uint8_t)g.blk_comp[threadIdx.x];
+	}
+	__syncthreads();
+}
+
+__device__ __forceinline__ void store_info(JhSubInfo *dst, const DecState &s)
+{
+	JhSubInfo r;
+	r.state = pack_state(s);
+	r.seg = s.seg;
+	r.nb = s.nb;
+#pragma unroll
+	for (int k = 0; k < JH_MAX_COMP; ++k) {
+		r.dc[k] = s.dc[k];
+	}
+	*dst = r;
+}
+
+// chain state carried from one sub-sequence into the next: counters restart, position/phase stay
+__device__ __forceinline__ void next_subsequence(DecState &s)
+{
+	s.reset = 0;
+	s.nb = 0;
+#pragma unroll
+	for (int k = 0; k < JH_MAX_COMP; ++k) {
+		s.dc[k] = 0;
+	}
+}
+
+#define STATE_SYNC_MASK 0x0000ffffffffffffull      // pos, c, z (the reset flag is not part of the parse state)
+
+// ===================================================================================== 2. intra-sequence
+
+struct HuffArgs {
+	JhDecodeWork w;
+	JhGeom g;
+	int round;                         // synchronisation round (inter kernel)
+};
+
+__global__ __launch_bounds__(256) void k_huff_sync_intra(const HuffArgs a)
+{
+	extern __shared__ __align__(16) unsigned char smem[];
+	JhHuffLut *luts = reinterpret_cast<JhHuffLut *>(smem);
+	__shared__ DecTables tb;
+	__shared__ JhSubInfo sinfo[256];
+
+	const JhDecodeWork &w = a.w;
+	const int f = blockIdx.y;
+	const JhDecFrame fr = w.frames[f];
+	const JhDecState fs = w.state[f];
+	const uint32_t total_bits = fs.cs_len * 8u;
+	const uint32_t nsub = (total_bits + JH_SUBSEQ_BITS - 1) / JH_SUBSEQ_BITS;
+	const uint32_t t0 = blockIdx.x * 256u;
+	if (t0 >= nsub) {
+		return;
+	}
+	load_tables(w, fr, luts, &tb, a.g);
+
+	const uint8_t *cs = w.cs + fr.cs_off;
+	const uint32_t *seg_start = w.seg_start + fr.seg_off;
+	const uint32_t nseg = min(fs.nseg, fr.seg_cap - 1);
+	const int tid = threadIdx.x;
+	const uint32_t t = t0 + tid;
+	const bool active = t < nsub;
+
+	DecState st;
+	st.pos = t * JH_SUBSEQ_BITS;
+	st.c = 0;
+	st.z = 0;
+	st.reset = 0;
+	st.nb = 0;
+	st.seg = 0;
+#pragma unroll
+	for (int k = 0; k < JH_MAX_COMP; ++k) {
+		st.dc[k] = 0;
+	}
+	if (active) {
+		st.seg = nseg > 1 ? find_segment(seg_start, nseg, st.pos >> 3) : 0u;
+		decode_span<false>(st, (t + 1) * JH_SUBSEQ_BITS, cs, total_bits, seg_start, nseg, luts, tb, a.g.B, nullptr, 0, 0);
+		store_info(&sinfo[tid], st);
+	}
+	__syncthreads();
+
+	// chains: thread `tid` walks on into sub-sequences tid+1, tid+2, ... until its state matches
+	bool running = active;
+	for (int step = 1; step < 256; ++step) {
+		const int j = tid + step;
+		const bool work = running && j < 256 && (t0 + j) < nsub;
+		if (work) {
+			next_subsequence(st);
+			decode_span<false>(st, (t0 + j + 1) * JH_SUBSEQ_BITS, cs, total_bits, seg_start, nseg, luts, tb, a.g.B, nullptr, 0, 0);
+			const unsigned long long old = sinfo[j].state;
+			const unsigned long long now = pack_state(st);
+			store_info(&sinfo[j], st);
+			if (((old ^ now) & STATE_SYNC_MASK) == 0) {
+				running = false;       // in step with the chain that started later: everything after is shared
+			}
+		} else {
+			running = false;
+		}
+		if (!__syncthreads_or(running ? 1 : 0)) {
+			break;
+		}
+	}
+	if (active) {
+		w.sub[fr.sub_off + t] = sinfo[tid];
+	}
+}
+
+// ===================================================================================== 3. inter-sequence
+
+// One thread per workgroup boundary of the intra kernel.  Thread b (b >= 1) carries the exit state of
+// sub-sequence 256*b - 1 into the next sequence until it matches.  Launched JH_SYNC_ITERS times; a
+// round in which no state changed proves the fixed point (then the remaining rounds exit at once).
+__global__ __launch_bounds__(64) void k_huff_sync_inter(const HuffArgs a)
+{
+	extern __shared__ __align__(16) unsigned char smem[];
+	JhHuffLut *luts = reinterpret_cast<JhHuffLut *>(smem);
+	__shared__ DecTables tb;
+
+	const JhDecodeWork &w = a.w;
+	const int f = blockIdx.y;
+	const JhDecFrame fr = w.frames[f];
+	JhDecState &fs = w.state[f];
+	if (a.round > 0 && fs.changed[a.round - 1] == 0) {
+		if (threadIdx.x == 0 && blockIdx.x == 0) {
+			fs.changed[a.round] = 0;   // converged earlier: stay converged
+		}
+		return;
+	}
+	const uint32_t total_bits = fs.cs_len * 8u;
+	const uint32_t nsub = (total_bits + JH_SUBSEQ_BITS - 1) / JH_SUBSEQ_BITS;
+	const uint32_t nbound = (nsub + 255) / 256;       // sequences; boundaries are 1 .. nbound-1
+	if (blockIdx.x * 64u + 1 >= nbound) {
+		return;
+	}
+	load_tables(w, fr, luts, &tb, a.g);
+	const uint32_t b = blockIdx.x * 64u + threadIdx.x + 1;
+	if (b >= nbound) {
+		return;
+	}
+	const uint8_t *cs = w.cs + fr.cs_off;
+	const uint32_t *seg_start = w.seg_start + fr.seg_off;
+	const uint32_t nseg = min(fs.nseg, fr.seg_cap - 1);
+	JhSubInfo *sub = w.sub + fr.sub_off;
+
+	const JhSubInfo prev = sub[b * 256 - 1];
+	DecState st;
+	st.pos = (uint32_t)(prev.state & 0xffffffffu);
+	st.c = (int)((prev.state >> 32) & 0xff);
+	st.z = (int)((prev.state >> 40) & 0xff);
+	st.seg = prev.seg;
+	if (st.c >= a.g.B || st.z > 63 || st.seg >= nseg) {
+		return;                        // torn / stale read: a later round redoes this boundary
+	}
+	unsigned changed = 0;
+	const uint32_t jend = min(nsub, (b + 1) * 256);
+	for (uint32_t j = b * 256; j < jend; ++j) {
+		next_subsequence(st);
+		decode_span<false>(st, (j + 1) * JH_SUBSEQ_BITS, cs, total_bits, seg_start, nseg, luts, tb, a.g.B, nullptr, 0, 0);
+		const unsigned long long old = sub[j].state;
+		const unsigned long long now = pack_state(st);
+		store_info(&sub[j], st);
+		if (((old ^ now) & STATE_SYNC_MASK) == 0) {
+			break;
+		}
+		changed = 1;
+	}
+	if (changed) {
+		atomicAdd(&fs.changed[a.round], 1u);
+	}
+}
+
+// ===================================================================================== 4. scan
+
+// One workgroup per frame: exclusive prefix over the sub-sequence records.
+//   blocks : plain sum (the reference's mblocks counter runs across restart markers, decoder.c:381)
+//   DC     : restart-segmented sum (predictors return to 0 at every boundary, decoder.c:371-373)
+__global__ __launch_bounds__(256) void k_huff_scan(const HuffArgs a)
+{
+	__shared__ int s_nb[256];
+	__shared__ int s_dc[JH_MAX_COMP][256];
+	__shared__ int s_rs[256];
+
+	const JhDecodeWork &w = a.w;
+	const int f = blockIdx.x;
+	const JhDecFrame fr = w.frames[f];
+	JhDecState &fs = w.state[f];
+	const uint32_t total_bits = fs.cs_len * 8u;
+	const uint32_t nsub = (total_bits + JH_SUBSEQ_BITS - 1) / JH_SUBSEQ_BITS;
+	const JhSubInfo *sub = w.sub + fr.sub_off;
+	JhSubStart *start = w.start + fr.sub_off;
+	const int tid = threadIdx.x;
+
+	int carry_nb = 0, carry_dc[JH_MAX_COMP] = {0, 0, 0, 0};
+	for (uint32_t t0 = 0; t0 < nsub; t0 += 256) {
+		const uint32_t t = t0 + tid;
+		JhSubInfo me;
+		me.state = 0;
+		me.seg = 0;
+		me.nb = 0;
+#pragma unroll
+		for (int k = 0; k < JH_MAX_COMP; ++k) {
+			me.dc[k] = 0;
+		}
+		if (t < nsub) {
+			me = sub[t];
+		}
+		int nb = me.nb, rs = (int)((me.state >> 48) & 1);
+		int dc[JH_MAX_COMP];
+#pragma unroll
+		for (int k = 0; k < JH_MAX_COMP; ++k) {
+			dc[k] = me.dc[k];
+		}
+		// inclusive Hillis-Steele scan with the segmented operator
+		for (int o = 1; o < 256; o <<= 1) {
+			s_nb[tid] = nb;
+			s_rs[tid] = rs;
+#pragma unroll
+			for (int k = 0; k < JH_MAX_COMP; ++k) {
+				s_dc[k][tid] = dc[k];
+			}
+			__syncthreads();
+			if (tid >= o) {
+				nb += s_nb[tid - o];
+				if (!rs) {
+#pragma unroll
+					for (int k = 0; k < JH_MAX_COMP; ++k) {
+						dc[k] += s_dc[k][tid - o];
+					}
+				}
+				rs |= s_rs[tid - o];
+			}
+			__syncthreads();
+		}
+		// fold in the carry of the previous tiles
+		const int inc_nb = carry_nb + nb;
+		int inc_dc[JH_MAX_COMP];
+#pragma unroll
+		for (int k = 0; k < JH_MAX_COMP; ++k) {
+			inc_dc[k] = rs ? dc[k] : carry_dc[k] + dc[k];
+		}
+		// publish inclusive values so that the neighbour can read its exclusive prefix
+		s_nb[tid] = inc_nb;
+#pragma unroll
+		for (int k = 0; k < JH_MAX_COMP; ++k) {
+			s_dc[k][tid] = inc_dc[k];
+		}
+		__syncthreads();
+		if (t < nsub) {
+			JhSubStart o;
+			if (tid == 0) {
+				o.blk = carry_nb;
+#pragma unroll
+				for (int k = 0; k < JH_MAX_COMP; ++k) {
+					o.pred[k] = carry_dc[k];
+				}
+			} else {
+				o.blk = s_nb[tid - 1];
+#pragma unroll
+				for (int k = 0; k < JH_MAX_COMP; ++k) {
+					o.pred[k] = s_dc[k][tid - 1];
+				}
+			}
+			if (t == 0) {
+				o.state = 0;           // a DC code of block 0 starts at bit 0
+				o.seg = 0;
+			} else {
+				const JhSubInfo p = sub[t - 1];
+				o.state = p.state & STATE_SYNC_MASK;
+				o.seg = p.seg;
+			}
+			start[t] = o;
+		}
+		const int last_nb = s_nb[255];
+		int last_dc[JH_MAX_COMP];
+#pragma unroll
+		for (int k = 0; k < JH_MAX_COMP; ++k) {
+			last_dc[k] = s_dc[k][255];
+		}
+		__syncthreads();
+		carry_nb = last_nb;
+#pragma unroll
+		for (int k = 0; k < JH_MAX_COMP; ++k) {
+			carry_dc[k] = last_dc[k];
+		}
+	}
+	if (tid == 0) {
+		fs.nblocks = (uint32_t)carry_nb;
+		// did the synchronisation reach its fixed point?
+		bool conv = false;
+		for (int r = 0; r < JH_SYNC_ITERS; ++r) {
+			conv = conv || fs.changed[r] == 0;
+		}
+		if (!conv) {
+			fs.status |= JH_ST_NOT_CONVERGED;
+		} else {
+			fs.status &= ~(uint32_t)JH_ST_NOT_CONVERGED;
+		}
+	}
+}
+
+// ===================================================================================== 5. write pass
+
+__global__ __launch_bounds__(256) void k_huff_write(const HuffArgs a)
+{
+	extern __shared__ __align__(16) unsigned char smem[];
+	JhHuffLut *luts = reinterpret_cast<JhHuffLut *>(smem);
+	__shared__ DecTables tb;
+
+	const JhDecodeWork &w = a.w;
+	const int f = blockIdx.y;
+	const JhDecFrame fr = w.frames[f];
+	const JhDecState fs = w.state[f];
+	const uint32_t total_bits = fs.cs_len * 8u;
+	const uint32_t nsub = (total_bits + JH_SUBSEQ_BITS - 1) / JH_SUBSEQ_BITS;
+	if (blockIdx.x * 256u >= nsub) {
+		return;
+	}
+	load_tables(w, fr, luts, &tb, a.g);
+	const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+	if (t >= nsub) {
+		return;
+	}
+	const uint8_t *cs = w.cs + fr.cs_off;
+	const uint32_t *seg_start = w.seg_start + fr.seg_off;
+	const uint32_t nseg = min(fs.nseg, fr.seg_cap - 1);
+	const JhSubStart s0 = w.start[fr.sub_off + t];
+
+	DecState st;
+	st.pos = (uint32_t)(s0.state & 0xffffffffu);
+	st.c = (int)((s0.state >> 32) & 0xff);
+	st.z = (int)((s0.state >> 40) & 0xff);
+	st.seg = s0.seg;
+	st.reset = 0;
+	st.nb = 0;
+#pragma unroll
+	for (int k = 0; k < JH_MAX_COMP; ++k) {
+		st.dc[k] = s0.pred[k];
+	}
+	if (st.c >= a.g.B || st.z > 63 || st.seg >= nseg) {
+		return;                        // only reachable when the synchronisation did not converge
+	}
+	decode_span<true>(st, (t + 1) * JH_SUBSEQ_BITS, cs, total_bits, seg_start, nseg, luts, tb, a.g.B,
+	                  w.coefs + (size_t)f * a.g.nblk * 64, s0.blk, a.g.nblk);
+}
+
+int jh_launch_huff_decode(const JhDecodeWork &w, const JhGeom &g, hipStream_t s, int extra_sync_rounds)
+{
+	HuffArgs a;
+	a.w = w;
+	a.g = g;
+	a.round = 0;
+	// one launch configuration for the batch: LDS for the largest table set of any frame
+	size_t lds = sizeof(JhHuffLut) * (size_t)w.max_luts;
+	dim3 gsub((w.max_subs + 255) / 256, w.nframes);
+	if (extra_sync_rounds == 0) {
+		hipLaunchKernelGGL(k_huff_sync_intra, gsub, dim3(256), lds, s, a);
+	}
+	const unsigned nbound = (w.max_subs + 255) / 256;
+	dim3 gb((nbound + 63) / 64, w.nframes);
+	for (int r = 0; r < JH_SYNC_ITERS; ++r) {
+		a.round = r;
+		hipLaunchKernelGGL(k_huff_sync_inter, gb, dim3(64), lds, s, a);
+	}
+	hipLaunchKernelGGL(k_huff_scan, dim3(w.nframes), dim3(256), 0, s, a);
+	hipLaunchKernelGGL(k_huff_write, gsub, dim3(256), lds, s, a);
+	return hipGetLastError() == hipSuccess ? 0 : -1;
+}

@@ -1,0 +1,509 @@
+// jpeg_amd/csrc/huffenc.hip -- entropy ENcoding on gfx950.
+//
+// Replaces the reference's serial loops
+//     write_ecs_dry (encoder.c:525-558) -> write_macroblock_dry (:466-518) -> write_block_dry (coeffs.c:312-363)
+//     write_ecs     (encoder.c:560-587) -> write_macroblock (:412-464)     -> write_block (coeffs.c:256-309)
+//       -> write_code (huffman.c:274-292) / write_extra_bits (:314-325) -> put_bit (io.c:43-63, one
+//          fwrite per byte) -> write_ecs_byte (io.c:277-290) -> flush_bits (io.c:65-87)
+// by data-parallel stages over the int16 scan-order coefficient buffer:
+//
+//   k_enc_histogram  symbol statistics per table (LDS histograms, one global atomic per used bin)
+//   k_enc_bitlen     bits per block (Figure F.2 walk with the table's code sizes) + workgroup sums,
+//                    plus the two conditions the reference assert()s / fails on
+//   k_enc_wg_scan    exclusive scan of the workgroup sums = bit offset of every 256-block group
+//   k_enc_pack       every thread re-walks its block and ORs its code words into an LDS image of the
+//                    workgroup's bit range (MSB first); the image is stored coalesced, the two shared
+//                    boundary words merged with atomicOr
+//   k_enc_ffcount / k_enc_ff_scan / k_enc_stuff
+//                    0xFF -> 0xFF 0x00 byte stuffing as count -> scan -> scatter, final 1-padding,
+//                    EOI appended
+//
+// The whole image is ONE entropy-coded segment, as in the reference (no restart markers: quirk Q2).
+// Integer work: the produced bytes are identical to write_ecs()'s.
+#include <hip/hip_runtime.h>
+#include "common.hpp"
+#include "kernels.hpp"
+
+#define WIN_WORDS 6144                // LDS image of one workgroup's bit range: 24 KB = 768 bits/block
+#define FF_CHUNK 4096
+
+struct EncArgs {
+	JhEncodeWork w;
+	JhGeom g;
+};
+
+// ---------------------------------------------------------------------------------------- block walk
+
+struct BlockRegs {
+	int w[32];                        // 64 int16 coefficients, zig-zag order, two per dword
+};
+
+__device__ __forceinline__ void load_block(const int16_t *src, BlockRegs &b)
+{
+#pragma unroll
+	for (int j = 0; j < 8; ++j) {
+		const int4 v = reinterpret_cast<const int4 *>(src)[j];
+		b.w[4 * j] = v.x;
+		b.w[4 * j + 1] = v.y;
+		b.w[4 * j + 2] = v.z;
+		b.w[4 * j + 3] = v.w;
+	}
+}
+
+__device__ __forceinline__ int coef_at(const BlockRegs &b, int i)   // i is a compile-time constant after unrolling
+{
+	return (i & 1) ? (b.w[i >> 1] >> 16) : (int)(short)(b.w[i >> 1] & 0xffff);
+}
+
+// encode_cat (coeffs.c:56-74): number of bits of |c|
+__device__ __forceinline__ int category(int c)
+{
+	const int m = c < 0 ? -c : c;
+	return 32 - __clz(m);             // __clz(0) = 32
+}
+
+// encode_extra (coeffs.c:76-83)
+__device__ __forceinline__ unsigned extra_bits(int c, int cat)
+{
+	return (unsigned)(c < 0 ? c - 1 : c) & ((1u << cat) - 1u);
+}
+
+// DC prediction as write_macroblock does it (encoder.c:443-458): the previous block of the SAME
+// component in scan order; 0 at the start of the scan (and of a restart interval, extension).
+__device__ __forceinline__ int dc_predictor(const int16_t *frame_coefs, int blk, const JhGeom &g, int ri)
+{
+	const int mcu = blk / g.B, k = blk - mcu * g.B;
+	const int comp = g.blk_comp[k];
+	if (k > g.comp_first[comp]) {
+		return frame_coefs[(size_t)(blk - 1) * 64];
+	}
+	if (mcu == 0 || (ri > 0 && mcu % ri == 0)) {
+		return 0;
+	}
+	const int last = g.comp_first[comp] + g.H[comp] * g.V[comp] - 1;
+	return frame_coefs[((size_t)(mcu - 1) * g.B + last) * 64];
+}
+
+// Figure F.2 (coeffs.c:276-306): calls sym(rs, cat, extra) for every AC symbol of the block.
+template <typename F>
+__device__ __forceinline__ void walk_ac(const BlockRegs &b, F &&sym)
+{
+	int r = 0;
+#pragma unroll
+	for (int i = 1; i < 64; ++i) {
+		const int c = coef_at(b, i);
+		if (c == 0) {
+			if (i == 63) {
+				sym(0, 0, 0u);                             // EOB
+			} else {
+				r++;
+			}
+		} else {
+			while (r > 15) {
+				sym(0xf0, 0, 0u);                          // ZRL
+				r -= 16;
+			}
+			const int cat = category(c);
+			sym((r << 4) | (cat & 15), cat, extra_bits(c, cat));
+			r = 0;
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------------------- histogram
+
+__global__ __launch_bounds__(256) void k_enc_histogram(const EncArgs a)
+{
+	__shared__ unsigned hist[4][257];
+	const JhEncodeWork &w = a.w;
+	const JhGeom &g = a.g;
+	const int f = blockIdx.y;
+	for (int i = threadIdx.x; i < 4 * 257; i += 256) {
+		(&hist[0][0])[i] = 0;
+	}
+	__syncthreads();
+	const int blk = blockIdx.x * 256 + threadIdx.x;
+	const int16_t *fc = w.coefs + (size_t)f * g.nblk * 64;
+	if (blk < g.nblk) {
+		BlockRegs b;
+		load_block(fc + (size_t)blk * 64, b);
+		const int comp = g.blk_comp[blk % g.B];
+		const int diff = coef_at(b, 0) - dc_predictor(fc, blk, g, w.restart_interval);
+		unsigned *hd = hist[0 * 2 + (g.Td[comp] & 1)];
+		unsigned *ha = hist[1 * 2 + (g.Ta[comp] & 1)];
+		atomicAdd(&hd[category(diff) & 15], 1u);           // coeffs.c:327
+		walk_ac(b, [&](int rs, int, unsigned) { atomicAdd(&ha[rs], 1u); });
+	}
+	__syncthreads();
+	unsigned *gh = w.hist + (size_t)f * 4 * 257;
+	for (int i = threadIdx.x; i < 4 * 257; i += 256) {
+		const unsigned v = (&hist[0][0])[i];
+		if (v) {
+			atomicAdd(&gh[i], v);
+		}
+	}
+}
+
+int jh_launch_enc_histogram(const JhEncodeWork &w, const JhGeom &g, hipStream_t s)
+{
+	EncArgs a;
+	a.w = w;
+	a.g = g;
+	hipMemsetAsync(w.hist, 0, (size_t)w.nframes * 4 * 257 * sizeof(uint32_t), s);
+	hipLaunchKernelGGL(k_enc_histogram, dim3(w.nwg, w.nframes), dim3(256), 0, s, a);
+	return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// ---------------------------------------------------------------------------------------- bit lengths
+
+__device__ __forceinline__ unsigned block_sum(unsigned v, unsigned *scratch)
+{
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) {
+		v += __shfl_down(v, o, 64);
+	}
+	if ((threadIdx.x & 63) == 0) {
+		scratch[threadIdx.x >> 6] = v;
+	}
+	__syncthreads();
+	const unsigned r = scratch[0] + scratch[1] + scratch[2] + scratch[3];
+	__syncthreads();
+	return r;
+}
+
+__device__ __forceinline__ unsigned block_excl(unsigned v, unsigned *scratch, unsigned *total)
+{
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	unsigned inc = v;
+#pragma unroll
+	for (int o = 1; o < 64; o <<= 1) {
+		const unsigned t = __shfl_up(inc, o, 64);
+		if (lane >= o) {
+			inc += t;
+		}
+	}
+	if (lane == 63) {
+		scratch[wv] = inc;
+	}
+	__syncthreads();
+	unsigned base = 0;
+	for (int i = 0; i < wv; ++i) {
+		base += scratch[i];
+	}
+	*total = scratch[0] + scratch[1] + scratch[2] + scratch[3];
+	__syncthreads();
+	return base + inc - v;
+}
+
+__global__ __launch_bounds__(256) void k_enc_bitlen(const EncArgs a)
+{
+	__shared__ uint32_t codes[4][256];
+	__shared__ unsigned scratch[4];
+	const JhEncodeWork &w = a.w;
+	const JhGeom &g = a.g;
+	const int f = blockIdx.y;
+	for (int i = threadIdx.x; i < 4 * 256; i += 256) {
+		(&codes[0][0])[i] = w.codes[(size_t)f * 4 + (i >> 8)].code[i & 255];
+	}
+	__syncthreads();
+	const int blk = blockIdx.x * 256 + threadIdx.x;
+	const int16_t *fc = w.coefs + (size_t)f * g.nblk * 64;
+	unsigned bits = 0, err = 0;
+	if (blk < g.nblk) {
+		BlockRegs b;
+		load_block(fc + (size_t)blk * 64, b);
+		const int comp = g.blk_comp[blk % g.B];
+		const int diff = coef_at(b, 0) - dc_predictor(fc, blk, g, w.restart_interval);
+		if (diff < -2047 || diff > 2047) {
+			err |= JH_EST_DC_RANGE;                        // assert (encoder.c:447)
+		}
+		const uint32_t *cd = codes[0 * 2 + (g.Td[comp] & 1)];
+		const uint32_t *ca = codes[1 * 2 + (g.Ta[comp] & 1)];
+		const int dcat = category(diff) & 15;
+		const unsigned ds = cd[dcat] & 0xffu;
+		if (ds == 0) {
+			err |= JH_EST_NO_CODE;                         // value_to_vlc() == -1 (huffman.c:252)
+		}
+		bits = ds + (unsigned)dcat;
+		walk_ac(b, [&](int rs, int cat, unsigned) {
+			const unsigned s = ca[rs] & 0xffu;
+			if (s == 0) {
+				err |= JH_EST_NO_CODE;
+			}
+			bits += s + (unsigned)cat;
+		});
+		w.bitlen[(size_t)f * g.nblk + blk] = (uint16_t)bits;
+	}
+	if (err) {
+		atomicOr(&w.state[f].status, err);
+	}
+	const unsigned total = block_sum(bits, scratch);
+	if (threadIdx.x == 0) {
+		w.wg_bits[(size_t)f * (w.nwg + 1) + blockIdx.x] = total;
+	}
+}
+
+// one workgroup per frame: exclusive scan of the workgroup sums, total, padding, boundary words
+__global__ __launch_bounds__(256) void k_enc_wg_scan(const EncArgs a)
+{
+	__shared__ unsigned scratch[4];
+	const JhEncodeWork &w = a.w;
+	const int f = blockIdx.x;
+	uint32_t *wg = w.wg_bits + (size_t)f * (w.nwg + 1);
+	uint32_t *us = w.us + (size_t)f * (w.us_stride / 4);
+	const uint32_t cap_bits = (uint32_t)((w.us_stride - 8) * 8);
+	unsigned carry = 0;
+	bool over = false;
+	for (int c0 = 0; c0 < w.nwg; c0 += 256) {
+		const int c = c0 + threadIdx.x;
+		const unsigned v = c < w.nwg ? wg[c] : 0u;
+		unsigned total;
+		const unsigned e = carry + block_excl(v, scratch, &total);
+		if (c < w.nwg) {
+			wg[c] = e;
+			if ((unsigned long long)e + v > cap_bits) {
+				over = true;
+			} else {
+				us[e >> 5] = 0;                            // word shared with the previous workgroup
+			}
+		}
+		if ((unsigned long long)carry + total > cap_bits) {
+			over = true;
+		}
+		carry += total;
+	}
+	if (over) {
+		atomicOr(&w.state[f].status, JH_EST_OVERFLOW);
+	}
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		JhEncState &st = w.state[f];
+		const unsigned T = carry;
+		wg[w.nwg] = T;
+		st.total_bits = T;
+		st.us_bytes = (T + 7) >> 3;
+		if (!(st.status & JH_EST_OVERFLOW)) {
+			// flush_bits (io.c:65-87): pad the last byte with 1s
+			const unsigned pad = (8 - (T & 7)) & 7;
+			const unsigned mask = pad ? (((1u << pad) - 1u) << (32 - (T & 31) - pad)) : 0u;
+			us[T >> 5] = __builtin_bswap32(mask);
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------------------- bit packing
+
+__global__ __launch_bounds__(256) void k_enc_pack(const EncArgs a)
+{
+	__shared__ uint32_t codes[4][256];
+	__shared__ unsigned scratch[4];
+	__shared__ uint32_t win[WIN_WORDS];
+	const JhEncodeWork &w = a.w;
+	const JhGeom &g = a.g;
+	const int f = blockIdx.y;
+	if (w.state[f].status & JH_EST_OVERFLOW) {
+		return;
+	}
+	for (int i = threadIdx.x; i < 4 * 256; i += 256) {
+		(&codes[0][0])[i] = w.codes[(size_t)f * 4 + (i >> 8)].code[i & 255];
+	}
+	const uint32_t *wg = w.wg_bits + (size_t)f * (w.nwg + 1);
+	const uint32_t r0 = wg[blockIdx.x], r1 = wg[blockIdx.x + 1];   // this workgroup's bit range
+	const int blk = blockIdx.x * 256 + threadIdx.x;
+	const int16_t *fc = w.coefs + (size_t)f * g.nblk * 64;
+	const bool have = blk < g.nblk;
+	const unsigned mylen = have ? w.bitlen[(size_t)f * g.nblk + blk] : 0u;
+	unsigned total;
+	const uint32_t start = r0 + block_excl(mylen, scratch, &total);   // barrier inside: codes[] visible after
+	if (r1 == r0) {
+		return;
+	}
+	BlockRegs b;
+	int diff = 0, comp = 0;
+	if (have) {
+		load_block(fc + (size_t)blk * 64, b);
+		comp = g.blk_comp[blk % g.B];
+		diff = coef_at(b, 0) - dc_predictor(fc, blk, g, w.restart_interval);
+	}
+	const uint32_t *cd = codes[0 * 2 + (g.Td[comp] & 1)];
+	const uint32_t *ca = codes[1 * 2 + (g.Ta[comp] & 1)];
+	uint32_t *us = w.us + (size_t)f * (w.us_stride / 4);
+
+	const uint32_t wfirst = r0 >> 5, wlast = (r1 - 1) >> 5;
+	for (uint32_t wbase = wfirst; wbase <= wlast; wbase += WIN_WORDS) {
+		for (int i = threadIdx.x; i < WIN_WORDS; i += 256) {
+			win[i] = 0;
+		}
+		__syncthreads();
+		// does my bit range [start, start + mylen) touch this window?
+		const uint32_t lo_bit = wbase << 5;
+		const unsigned long long hi_bit = ((unsigned long long)wbase + WIN_WORDS) << 5;
+		if (have && mylen && (unsigned long long)start + mylen > lo_bit && start < hi_bit) {
+			unsigned long long acc = 0;                    // bits collected, left aligned
+			int nacc = (int)(start & 31u);                 // the word's leading bits belong to my predecessor
+			uint32_t widx = start >> 5;
+			auto put = [&](unsigned code, int len) {       // len <= 31
+				if (len <= 0) {
+					return;                                // symbol without code: flagged by k_enc_bitlen
+				}
+				acc |= (unsigned long long)code << (64 - nacc - len);
+				nacc += len;
+				if (nacc >= 32) {
+					const uint32_t rel = widx - wbase;     // unsigned: words before the window wrap to huge
+					if (rel < WIN_WORDS) {
+						atomicOr(&win[rel], (uint32_t)(acc >> 32));
+					}
+					acc <<= 32;
+					nacc -= 32;
+					widx++;
+				}
+			};
+			const int dcat = category(diff) & 15;
+			const uint32_t dcode = cd[dcat];               // write_dc (coeffs.c:110-126)
+			put(((dcode >> 8) << dcat) | extra_bits(diff, dcat), (int)(dcode & 0xffu) + dcat);
+			walk_ac(b, [&](int rs, int cat, unsigned extra) {   // write_ac (coeffs.c:164-194)
+				const uint32_t e = ca[rs];
+				put(((e >> 8) << cat) | extra, (int)(e & 0xffu) + cat);
+			});
+			if (nacc > 0) {
+				const uint32_t rel = widx - wbase;
+				if (rel < WIN_WORDS) {
+					atomicOr(&win[rel], (uint32_t)(acc >> 32));
+				}
+			}
+		}
+		__syncthreads();
+		// store the image: whole words plainly, the (at most two) words shared with neighbours by OR
+		const uint32_t nw = min((uint32_t)WIN_WORDS, wlast - wbase + 1);
+		for (uint32_t i = threadIdx.x; i < nw; i += 256) {
+			const uint32_t wi = wbase + i;
+			const uint32_t v = __builtin_bswap32(win[i]);  // MSB-first bit stream -> byte order
+			const bool whole = (wi << 5) >= r0 && ((unsigned long long)(wi + 1) << 5) <= r1;
+			if (whole) {
+				us[wi] = v;
+			} else if (v) {
+				atomicOr(&us[wi], v);
+			}
+		}
+		__syncthreads();
+	}
+}
+
+// ---------------------------------------------------------------------------------------- byte stuffing
+
+__global__ __launch_bounds__(256) void k_enc_ffcount(const EncArgs a)
+{
+	__shared__ unsigned scratch[4];
+	const JhEncodeWork &w = a.w;
+	const int f = blockIdx.y;
+	const JhEncState st = w.state[f];
+	const uint32_t nbytes = (st.status & JH_EST_OVERFLOW) ? 0u : st.us_bytes;
+	const uint32_t base = blockIdx.x * FF_CHUNK + threadIdx.x * 16;
+	if (blockIdx.x * (uint32_t)FF_CHUNK >= nbytes) {
+		return;
+	}
+	unsigned cnt = 0;
+	if (base < nbytes) {
+		const uint4 v = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(w.us) + (size_t)f * w.us_stride + base);
+		const unsigned ws[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+		for (int i = 0; i < 16; ++i) {
+			const unsigned byte = (ws[i >> 2] >> (8 * (i & 3))) & 0xffu;
+			cnt += (base + i < nbytes && byte == 0xffu) ? 1u : 0u;
+		}
+	}
+	const unsigned total = block_sum(cnt, scratch);
+	if (threadIdx.x == 0) {
+		w.chunk_ff[(size_t)f * w.nchunk + blockIdx.x] = total;
+	}
+}
+
+__global__ __launch_bounds__(256) void k_enc_ff_scan(const EncArgs a)
+{
+	__shared__ unsigned scratch[4];
+	const JhEncodeWork &w = a.w;
+	const int f = blockIdx.x;
+	JhEncState &st = w.state[f];
+	const uint32_t nbytes = (st.status & JH_EST_OVERFLOW) ? 0u : st.us_bytes;
+	const int nch = (int)((nbytes + FF_CHUNK - 1) / FF_CHUNK);
+	uint32_t *ff = w.chunk_ff + (size_t)f * w.nchunk;
+	unsigned carry = 0;
+	for (int c0 = 0; c0 < nch; c0 += 256) {
+		const int c = c0 + threadIdx.x;
+		const unsigned v = c < nch ? ff[c] : 0u;
+		unsigned total;
+		const unsigned e = carry + block_excl(v, scratch, &total);
+		if (c < nch) {
+			ff[c] = e;
+		}
+		carry += total;
+	}
+	if (threadIdx.x == 0) {
+		const uint32_t ecs = nbytes + carry;
+		st.ecs_bytes = ecs;
+		uint8_t *out = w.out + (size_t)f * w.out_stride + w.hdr_len[f];
+		if ((size_t)w.hdr_len[f] + ecs + 2 <= w.out_stride) {
+			out[ecs] = 0xff;                               // EOI (encoder.c:402-410)
+			out[ecs + 1] = 0xd9;
+		} else {
+			st.status |= JH_EST_OVERFLOW;
+		}
+	}
+}
+
+__global__ __launch_bounds__(256) void k_enc_stuff(const EncArgs a)
+{
+	__shared__ unsigned scratch[4];
+	const JhEncodeWork &w = a.w;
+	const int f = blockIdx.y;
+	const JhEncState st = w.state[f];
+	if (st.status & JH_EST_OVERFLOW) {
+		return;
+	}
+	const uint32_t nbytes = st.us_bytes;
+	if (blockIdx.x * (uint32_t)FF_CHUNK >= nbytes) {
+		return;
+	}
+	const uint32_t base = blockIdx.x * FF_CHUNK + threadIdx.x * 16;
+	unsigned bytes[16];
+	unsigned cnt = 0;
+	if (base < nbytes) {
+		const uint4 v = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(w.us) + (size_t)f * w.us_stride + base);
+		const unsigned ws[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+		for (int i = 0; i < 16; ++i) {
+			bytes[i] = (ws[i >> 2] >> (8 * (i & 3))) & 0xffu;
+			cnt += (base + i < nbytes && bytes[i] == 0xffu) ? 1u : 0u;
+		}
+	}
+	unsigned total;
+	unsigned before = w.chunk_ff[(size_t)f * w.nchunk + blockIdx.x] + block_excl(cnt, scratch, &total);
+	if (base >= nbytes) {
+		return;
+	}
+	uint8_t *out = w.out + (size_t)f * w.out_stride + w.hdr_len[f];
+	uint32_t o = base + before;                            // write_ecs_byte (io.c:277-290)
+#pragma unroll
+	for (int i = 0; i < 16; ++i) {
+		if (base + i < nbytes) {
+			out[o++] = (uint8_t)bytes[i];
+			if (bytes[i] == 0xffu) {
+				out[o++] = 0x00;
+			}
+		}
+	}
+}
+
+int jh_launch_enc_entropy(const JhEncodeWork &w, const JhGeom &g, hipStream_t s)
+{
+	EncArgs a;
+	a.w = w;
+	a.g = g;
+	hipLaunchKernelGGL(k_enc_bitlen, dim3(w.nwg, w.nframes), dim3(256), 0, s, a);
+	hipLaunchKernelGGL(k_enc_wg_scan, dim3(w.nframes), dim3(256), 0, s, a);
+	hipLaunchKernelGGL(k_enc_pack, dim3(w.nwg, w.nframes), dim3(256), 0, s, a);
+	hipLaunchKernelGGL(k_enc_ffcount, dim3(w.nchunk, w.nframes), dim3(256), 0, s, a);
+	hipLaunchKernelGGL(k_enc_ff_scan, dim3(w.nframes), dim3(256), 0, s, a);
+	hipLaunchKernelGGL(k_enc_stuff, dim3(w.nchunk, w.nframes), dim3(256), 0, s, a);
+	return hipGetLastError() == hipSuccess ? 0 : -1;
+}

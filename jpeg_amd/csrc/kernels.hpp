@@ -1,0 +1,100 @@
+// jpeg_amd/csrc/kernels.hpp -- launchers of the HIP kernels (internal).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include "common.hpp"
+
+// ---- per-frame descriptors shared by the entropy kernels ---------------------------------------
+
+struct JhDecFrame {               // written by the host in prepare()
+	uint32_t raw_begin;           // first ECS byte (absolute offset in the raw codestream buffer)
+	uint32_t raw_end;             // end of the frame's file in the raw buffer
+	uint32_t cs_off;              // unstuffed stream of this frame (bytes, 16-byte aligned)
+	uint32_t sub_off;             // first sub-sequence record of this frame
+	uint32_t sub_cap;             // records reserved
+	uint32_t seg_off;             // first entry of this frame in the restart-segment table
+	uint32_t seg_cap;             // entries reserved (incl. sentinel)
+	uint32_t chunk_off;           // first entry in the per-chunk count arrays
+	uint32_t nchunk;
+	uint32_t lut_off;             // first JhHuffLut of this frame
+	uint32_t n_lut;
+	uint8_t  blk_dc[JH_MAX_MCU_BLOCKS];   // lut slot per block of the MCU
+	uint8_t  blk_ac[JH_MAX_MCU_BLOCKS];
+};
+
+enum {                            // JhDecState.status bits
+	JH_ST_SEG_OVERFLOW = 1,       // more restart segments than reserved
+	JH_ST_NOT_CONVERGED = 2,      // speculative decode needs more synchronisation rounds
+};
+
+struct JhDecState {               // written by the device
+	uint32_t term_pos;            // absolute position of the marker that ends the ECS (or raw_end)
+	uint32_t cs_len;              // bytes of unstuffed entropy-coded data
+	uint32_t nseg;                // restart segments
+	uint32_t status;
+	uint32_t changed[JH_SYNC_ITERS + 1];
+	uint32_t nblocks;             // blocks decoded (for diagnostics)
+	uint32_t term_marker;         // second byte of the marker at term_pos (0xd9 = EOI)
+};
+
+struct JhDecodeWork {             // device pointers of one decoder batch
+	const uint8_t *raw;           // all codestreams
+	uint8_t *cs;                  // unstuffed streams
+	uint32_t *seg_start;          // byte offset of every restart segment inside cs (per frame slices)
+	uint32_t *chunk_kept, *chunk_rst;
+	JhSubInfo *sub;               // exit records
+	JhSubStart *start;            // entry records for the write pass
+	const JhDecFrame *frames;
+	JhDecState *state;
+	const JhHuffLut *luts;
+	int16_t *coefs;
+	int nframes;
+	uint32_t max_chunks;          // per frame (grid size)
+	uint32_t max_subs;            // per frame (grid size)
+	uint32_t max_luts;            // Huffman tables of the frame that uses most (LDS size)
+};
+
+int jh_launch_ecs_unstuff(const JhDecodeWork &w, hipStream_t s);
+int jh_launch_huff_decode(const JhDecodeWork &w, const JhGeom &g, hipStream_t s, int extra_sync_rounds);
+
+int jh_launch_decode_pixels(const JhGeom &g, int nframes, const int16_t *coefs, const JhQuant *quant,
+                            void *out, size_t frame_stride, hipStream_t stream);
+int jh_launch_encode_pixels(const JhGeom &g, int nframes, const void *in, size_t frame_stride,
+                            const JhQuant *quant_raster, int16_t *coefs, hipStream_t stream);
+
+// ---- entropy encoder -------------------------------------------------------------------------------
+
+enum {                            // JhEncState.status bits
+	JH_EST_DC_RANGE = 1,          // |DC difference| > 2047 (assert in the reference, encoder.c:447)
+	JH_EST_NO_CODE = 2,           // symbol missing from the table (value_to_vlc == -1)
+	JH_EST_OVERFLOW = 4,          // output buffer too small
+};
+
+struct JhEncState {               // per frame, written by the device
+	uint32_t status;
+	uint32_t total_bits;          // entropy-coded bits before padding
+	uint32_t us_bytes;            // bytes of the unstuffed stream (after padding with 1s)
+	uint32_t ecs_bytes;           // bytes after 0xFF stuffing (+ RSTn markers)
+};
+
+struct JhEncodeWork {
+	const int16_t *coefs;         // [frame][nblk][64] zig-zag
+	const JhHuffEnc *codes;       // [frame][Tc*2+Th]: DC0, DC1, AC0, AC1 (table ids 0/1 only, as the encoder uses)
+	uint32_t *hist;               // [frame][4][257] symbol counts (optimised tables)
+	uint16_t *bitlen;             // [frame][nblk]
+	uint32_t *wg_bits;            // [frame][nwg] per-workgroup sums, then exclusive bases
+	uint32_t *us;                 // unstuffed streams, frame stride us_stride bytes
+	size_t us_stride;
+	uint32_t *chunk_ff;           // [frame][nchunk] 0xFF counts per chunk, then exclusive bases
+	uint8_t *out;                 // final codestreams: frame stride out_stride, ECS starts at hdr_len[frame]
+	size_t out_stride;
+	const uint32_t *hdr_len;      // [frame]
+	JhEncState *state;
+	int nframes;
+	int nwg;                      // workgroups (256 blocks each) per frame
+	int nchunk;                   // stuffing chunks per frame (capacity)
+	int restart_interval;         // MCUs, 0 = none
+};
+
+int jh_launch_enc_histogram(const JhEncodeWork &w, const JhGeom &g, hipStream_t s);
+int jh_launch_enc_entropy(const JhEncodeWork &w, const JhGeom &g, hipStream_t s);

@@ -1,0 +1,55 @@
+"""CPU-side checks of the C-ABI boundary: the shared library loads and exports every symbol that
+include/jpeg_amd.h declares.  No compute calls (those need a GPU: tests/test_gpu_*.py)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built_lib():
+    from jpeg_amd import binding
+    if not os.path.exists(binding.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    return binding
+
+
+def test_header_symbols_are_exported(built_lib):
+    hdr = open(os.path.join(ROOT, "include", "jpeg_amd.h")).read()
+    declared = sorted(set(re.findall(r"\b(jpeg_hip_[a-z_]+)\s*\(", hdr)))
+    assert len(declared) >= 25
+    L = C.CDLL(built_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(L, name), "missing export: " + name
+    assert sorted(built_lib.EXPORTS) == declared
+
+
+def test_every_entry_point_cites_the_reference(built_lib):
+    hdr = open(os.path.join(ROOT, "include", "jpeg_amd.h")).read()
+    for ref in ("decoder.c:364", "decoder.c:456", "encoder.c:176", "encoder.c:525", "decoder.c:661",
+                "decoder.c:687", "encoder.c:647", "common.h:15-31"):
+        assert ref in hdr
+
+
+def test_struct_layouts_match_header(built_lib):
+    # jpeg_hip_frame_info: 4 + 6*4 + 6 + 2*4 + 4 ints
+    assert C.sizeof(built_lib.FrameInfo) == 4 * (4 + 24 + 6 + 8 + 4)
+    assert C.sizeof(built_lib.Params) == 16
+
+
+def test_fails_loudly_without_gpu(built_lib):
+    L = built_lib.lib()
+    if L.jpeg_hip_device_count() > 0:
+        pytest.skip("a GPU is visible here")
+    h = C.c_void_p()
+    assert L.jpeg_hip_decoder_create(C.byref(h), 0) == built_lib.RET_FAILURE_LOGIC_ERROR
+    assert not h
+    assert L.jpeg_hip_encoder_create(C.byref(h), 0) == built_lib.RET_FAILURE_LOGIC_ERROR
+    with pytest.raises(built_lib.JpegError):
+        built_lib.Decoder()
+    # the drop-in entry points refuse too (no silent CPU path)
+    assert L.jpeg_hip_process_jpeg_file(b"/nonexistent.jpg", None) == 0x1002  # RET_FAILURE_FILE_OPEN first
