@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X JPEG hot path (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--frames F]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (config.workload): BASELINE.json's metric configuration, 4K (3840x2160) 8-bit 4:2:0 q90,
+default Huffman tables, no restart markers -- the stream the reference encoder itself writes.  One
+STEP = one pass of the hot path over one batch of F synthetic frames per GPU: the batch of
+codestreams is DECODED (un-stuffing, speculative Huffman decode, IDCT, colour) and the batch of
+images is ENCODED (colour, FDCT, quantise, Huffman bit-packing, stuffing).  Inputs are resident in
+HBM before the timed region; outputs stay in HBM.  value = pixels that went through decode AND
+encode per second, whole job (all ranks).  Frames shard across ranks with no data-path
+collective (Motion-JPEG semantics) => "scaling": "weak".
+
+Extra keys: decode / encode rates measured separately, the MJPEG (1080p 4:2:2 q85) frame rate,
+"roofline" for the dominant kernel (HIP-event time per launch against algorithmic bytes,
+SURVEY.md section 8d) and "cpu_baseline" (the compiled reference, oracle/_ref, on one host core).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+
+
+def make_batch(binding, synth, name, nframes, device, distinct=4):
+    """Synthetic frames -> (device tensor of PPM bodies, list of JPEG codestreams from OUR encoder
+    (bit-exact vs the oracle, tests/test_gpu_parity.py), geometry info)."""
+    X, Y, nc, P, H, V, q, opt, safe, seed = synth.CONFIGS[name]
+    base = [synth.synth_image(X, Y, nc, P, seed, safe, frame=i) for i in range(min(distinct, nframes))]
+    imgs = [base[i % len(base)] for i in range(nframes)]
+    enc = binding.Encoder(device)
+    enc.configure(nframes, X, Y, nc, P, H, V, q, opt)
+    samples = enc.upload(imgs)
+    enc.run(samples)
+    st, ln = enc.sync()
+    assert all(s == 0 for s in st), st
+    jpgs = [enc.jpeg(f, ln[f]) for f in range(nframes)]
+    return enc, samples, jpgs, imgs, dict(X=X, Y=Y, nc=nc, P=P, H=H, V=V, q=q, opt=opt)
+
+
+def timed(torch, fn, steps, warmup, dist):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([t], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        t = float(tt.item())
+    return t
+
+
+def kernel_times(obj, run, torch, reps=5):
+    """Average per-kernel device time (ms) over reps launches, hipEvents on the launch stream."""
+    obj.set_timing(True)
+    acc = {}
+    for _ in range(reps):
+        run()
+        torch.cuda.synchronize()
+        for k, v in obj.timing().items():
+            acc[k] = acc.get(k, 0.0) + v
+    obj.set_timing(False)
+    return {k: v / reps for k, v in acc.items()}
+
+
+def cpu_baseline(imgs, jpgs, cfg, budget_s=20.0):
+    """The compiled reference (oracle/_ref: unmodified sources) on ONE host core: decode + encode of
+    whole 4K frames, in process, files in memory/tmpfs.  Bounded sample (~10-30 s)."""
+    try:
+        from oracle.pyoracle import Reference
+        ref = Reference()
+        kind = "reference"
+        enc = lambda im: ref.encode(im, P=cfg["P"], H=cfg["H"], V=cfg["V"], q=cfg["q"], optimize=cfg["opt"])
+        dec = lambda j: ref.decode(j)
+    except Exception:
+        from oracle.pyoracle import Oracle
+        orc = Oracle()
+        kind = "port"
+        enc = lambda im: orc.encode(im, P=cfg["P"], H=cfg["H"], V=cfg["V"], q=cfg["q"], optimize=cfg["opt"])
+        dec = lambda j: orc.decode(j)
+    pix = cfg["X"] * cfg["Y"]
+    n = 0
+    t_dec = t_enc = 0.0
+    t_start = time.perf_counter()
+    while n < len(imgs) and (n == 0 or time.perf_counter() - t_start < budget_s):
+        t0 = time.perf_counter()
+        e, _, _ = dec(jpgs[n])
+        t1 = time.perf_counter()
+        e2, _, _ = enc(imgs[n])
+        t2 = time.perf_counter()
+        assert e == 0 and e2 == 0
+        t_dec += t1 - t0
+        t_enc += t2 - t1
+        n += 1
+    return {
+        "value": round(n * pix / (t_dec + t_enc) / 1e6, 3), "unit": "Mpix/s", "cores": 1, "kind": kind,
+        "sample": "%d x (decode + encode) of a 4K 4:2:0 q90 frame, in-process, %.1f s" % (n, t_dec + t_enc),
+        "decode_mpix_s": round(n * pix / t_dec / 1e6, 3), "encode_mpix_s": round(n * pix / t_enc / 1e6, 3),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=16, help="4K frames per GPU per step")
+    ap.add_argument("--mjpeg-frames", type=int, default=64, help="1080p frames per GPU per step (extra line)")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-mjpeg", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist_mod.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        dist = dist_mod
+    else:
+        torch.cuda.set_device(local)
+    from jpeg_amd import binding, synth
+
+    dev = local
+    F = args.frames
+    enc, samples, jpgs, imgs, cfg = make_batch(binding, synth, "metric_4k_420_q90", F, dev)
+    dec = binding.Decoder(dev)
+    dec.prepare(jpgs)
+    out = dec.alloc_output()
+    pix = cfg["X"] * cfg["Y"]
+
+    def step():
+        dec.run(out)
+        enc.run(samples)
+
+    # correctness guard inside the bench: the decoded batch must be what the encoder was fed (lossy bound)
+    dec.run(out)
+    st = dec.sync()
+    assert all(s == 0 for s in st), st
+    got = dec.to_arrays(out)[0]
+    assert np.abs(got.astype(int) - imgs[0].astype(int)).max() < 64
+
+    t = timed(torch, step, args.steps, args.warmup, dist)
+    assert all(s == 0 for s in dec.sync()) and all(s == 0 for s in enc.sync()[0])
+    value = world * F * pix * args.steps / t / 1e6
+
+    t_d = timed(torch, lambda: dec.run(out), args.steps, 1, dist)
+    t_e = timed(torch, lambda: enc.run(samples), args.steps, 1, dist)
+
+    res = {
+        "metric": "Mpix/s decode+encode, 4K 4:2:0 q90 (every pixel is decoded AND encoded once per step)",
+        "value": round(value, 1), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(t / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32+f64 pixel maths (bit-exact), u8/int16 entropy coding", "data": "synthetic",
+        "config": {"workload": "metric_4k_420_q90: 3840x2160 8-bit 4:2:0 q90, default Huffman tables, no restart markers",
+                   "frames_per_gpu_per_step": F, "parallelism": "frames sharded over %d GPU(s), no collectives" % world},
+        "decode_mpix_s": round(world * F * pix * args.steps / t_d / 1e6, 1),
+        "encode_mpix_s": round(world * F * pix * args.steps / t_e / 1e6, 1),
+    }
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel, live HIP-event timing on the launch stream ----
+        kd = kernel_times(dec, lambda: dec.run(out), torch)
+        ke = kernel_times(enc, lambda: enc.run(samples), torch)
+        allk = dict(kd)
+        allk.update(ke)
+        dom = max(allk, key=allk.get)
+        jpg_bytes = sum(len(j) for j in jpgs)
+        alg_bytes = F * pix * cfg["nc"] + jpg_bytes        # W*H*Nc*s + B_jpeg per frame
+        achieved = alg_bytes / (allk[dom] * 1e-3) / 1e9
+        res["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                           "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                           "alg_bytes_per_launch": alg_bytes, "kernel_ms": round(allk[dom], 4)}
+        res["kernel_ms"] = {k: round(v, 4) for k, v in sorted(allk.items(), key=lambda kv: -kv[1])}
+        res["pipeline_hbm_frac"] = {"decode": round(alg_bytes / (t_d / args.steps) / 1e9 / HBM_PEAK_GBS, 5),
+                                    "encode": round(alg_bytes / (t_e / args.steps) / 1e9 / HBM_PEAK_GBS, 5)}
+
+    if not args.no_mjpeg:
+        # ---- Motion JPEG: 1080p 4:2:2 q85 frames, sharded over ranks ---------------------------
+        Fm = args.mjpeg_frames
+        enc.close()
+        dec.close()
+        del out, samples
+        enc2, samples2, jpgs2, imgs2, cfg2 = make_batch(binding, synth, "c5_1080p_422_q85", Fm, dev, distinct=4)
+        dec2 = binding.Decoder(dev)
+        dec2.prepare(jpgs2)
+        out2 = dec2.alloc_output()
+        td = timed(torch, lambda: dec2.run(out2), args.steps, 2, dist)
+        te = timed(torch, lambda: enc2.run(samples2), args.steps, 2, dist)
+        assert all(s == 0 for s in dec2.sync()) and all(s == 0 for s in enc2.sync()[0])
+        res["mjpeg_1080p_422_q85"] = {"decode_frames_per_s": round(world * Fm * args.steps / td, 1),
+                                      "encode_frames_per_s": round(world * Fm * args.steps / te, 1),
+                                      "frames_per_gpu_per_step": Fm, "bytes_per_frame": len(jpgs2[0])}
+
+    if rank == 0 and world == 1 and not args.no_cpu:
+        res["cpu_baseline"] = cpu_baseline(imgs, jpgs, cfg)
+    if rank == 0:
+        print(json.dumps(res))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

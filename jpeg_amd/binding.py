@@ -127,9 +127,9 @@ def _stream_ptr(device):
 
 
 def _timing(fn, handle):
-    names = (C.c_char_p * 16)()
-    ms = (C.c_float * 16)()
-    n = fn(handle, names, ms, 16)
+    names = (C.c_char_p * 32)()
+    ms = (C.c_float * 32)()
+    n = fn(handle, names, ms, 32)
     return {names[i].decode(): float(ms[i]) for i in range(n)}
 
 

@@ -123,6 +123,9 @@ struct StageTimer {
 		}
 		return k;
 	}
+	static void hook_begin(void *c, const char *n, hipStream_t s) { ((StageTimer *)c)->begin(n, s); }
+	static void hook_end(void *c, hipStream_t s) { ((StageTimer *)c)->end(s); }
+	JhTimerHook hook() { return JhTimerHook{hook_begin, hook_end, on ? this : nullptr}; }
 	~StageTimer()
 	{
 		for (hipEvent_t e : ev) {
@@ -427,14 +430,13 @@ __global__ void k_dec_reset_rounds(JhDecState *st, int n)
 static int decoder_launch(jpeg_hip_decoder *dec, hipStream_t s, bool resync_only)
 {
 	const JhDecodeWork &w = dec->work;
+	const JhTimerHook th = dec->timer.hook();
 	const size_t coef_bytes = (size_t)dec->nframes * dec->g.nblk * 64 * sizeof(int16_t);
 	if (!resync_only) {
-		dec->timer.begin("unstuff", s);
 		hipLaunchKernelGGL(k_dec_init, dim3((dec->nframes + 63) / 64), dim3(64), 0, s, dec->d_state, dec->nframes);
-		if (jh_launch_ecs_unstuff(w, s)) {
+		if (jh_launch_ecs_unstuff(w, s, &th)) {
 			return RET_FAILURE_LOGIC_ERROR;
 		}
-		dec->timer.end(s);
 	} else {
 		hipLaunchKernelGGL(k_dec_reset_rounds, dim3((dec->nframes + 63) / 64), dim3(64), 0, s, dec->d_state, dec->nframes);
 	}
@@ -442,12 +444,10 @@ static int decoder_launch(jpeg_hip_decoder *dec, hipStream_t s, bool resync_only
 	// alloc_buffers() zero-fills int_buffer (common.c:129): blocks the stream never reaches stay 0
 	HIPCHK(hipMemsetAsync(dec->d_coefs, 0, coef_bytes, s));
 	dec->timer.end(s);
-	dec->timer.begin("huffman", s);
-	if (jh_launch_huff_decode(w, dec->g, s, resync_only ? 1 : 0)) {
+	if (jh_launch_huff_decode(w, dec->g, s, resync_only ? 1 : 0, &th)) {
 		return RET_FAILURE_LOGIC_ERROR;
 	}
-	dec->timer.end(s);
-	dec->timer.begin("pixels", s);
+	dec->timer.begin("k_decode_pixels", s);
 	if (jh_launch_decode_pixels(dec->g, dec->nframes, dec->d_coefs, dec->d_quant, dec->last_out, dec->last_stride, s)) {
 		return RET_FAILURE_LOGIC_ERROR;
 	}
@@ -760,7 +760,8 @@ extern "C" int jpeg_hip_encoder_run(jpeg_hip_encoder *enc, const void *d_samples
 	enc->timer.reset();
 	const JhEncodeWork &w = enc->work;
 	HIPCHK(hipMemsetAsync(enc->d_state, 0, enc->nframes * sizeof(JhEncState), s));
-	enc->timer.begin("pixels", s);
+	const JhTimerHook th = enc->timer.hook();
+	enc->timer.begin("k_encode_pixels", s);
 	if (jh_launch_encode_pixels(g, enc->nframes, d_samples, frame_stride, enc->d_quant, enc->d_coefs, s)) {
 		return RET_FAILURE_LOGIC_ERROR;
 	}
@@ -768,11 +769,9 @@ extern "C" int jpeg_hip_encoder_run(jpeg_hip_encoder *enc, const void *d_samples
 	if (enc->prm.optimize) {
 		// write_ecs_dry() (encoder.c:525-558): histograms on the device, Annex K.2 on the host
 		// (<= 257 symbols per table, serial: SURVEY.md 8a-a18), tables back to the device.
-		enc->timer.begin("histogram", s);
-		if (jh_launch_enc_histogram(w, g, s)) {
+		if (jh_launch_enc_histogram(w, g, s, &th)) {
 			return RET_FAILURE_LOGIC_ERROR;
 		}
-		enc->timer.end(s);
 		std::vector<uint32_t> hist((size_t)enc->nframes * 4 * 257);
 		HIPCHK(hipMemcpyAsync(hist.data(), enc->d_hist, hist.size() * 4, hipMemcpyDeviceToHost, s));
 		HIPCHK(hipStreamSynchronize(s));
@@ -797,11 +796,9 @@ extern "C" int jpeg_hip_encoder_run(jpeg_hip_encoder *enc, const void *d_samples
 			return err;
 		}
 	}
-	enc->timer.begin("entropy", s);
-	if (jh_launch_enc_entropy(w, g, s)) {
+	if (jh_launch_enc_entropy(w, g, s, &th)) {
 		return RET_FAILURE_LOGIC_ERROR;
 	}
-	enc->timer.end(s);
 	enc->ran = true;
 	return RET_SUCCESS;
 }

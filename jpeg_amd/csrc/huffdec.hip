@@ -257,12 +257,18 @@ __global__ __launch_bounds__(256) void k_ecs_compact(JhDecodeWork w)
 	}
 }
 
-int jh_launch_ecs_unstuff(const JhDecodeWork &w, hipStream_t s)
+int jh_launch_ecs_unstuff(const JhDecodeWork &w, hipStream_t s, const JhTimerHook *th)
 {
 	dim3 grid(w.max_chunks, w.nframes);
+	JH_T_BEGIN(th, "k_ecs_scan", s);
 	hipLaunchKernelGGL(k_ecs_scan, grid, dim3(256), 0, s, w);
+	JH_T_END(th, s);
+	JH_T_BEGIN(th, "k_ecs_chunk_scan", s);
 	hipLaunchKernelGGL(k_ecs_chunk_scan, dim3(w.nframes), dim3(256), 0, s, w);
+	JH_T_END(th, s);
+	JH_T_BEGIN(th, "k_ecs_compact", s);
 	hipLaunchKernelGGL(k_ecs_compact, grid, dim3(256), 0, s, w);
+	JH_T_END(th, s);
 	return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -795,7 +801,7 @@ __global__ __launch_bounds__(256) void k_huff_write(const HuffArgs a)
 	                  w.coefs + (size_t)f * a.g.nblk * 64, s0.blk, a.g.nblk);
 }
 
-int jh_launch_huff_decode(const JhDecodeWork &w, const JhGeom &g, hipStream_t s, int extra_sync_rounds)
+int jh_launch_huff_decode(const JhDecodeWork &w, const JhGeom &g, hipStream_t s, int extra_sync_rounds, const JhTimerHook *th)
 {
 	HuffArgs a;
 	a.w = w;
@@ -805,15 +811,23 @@ int jh_launch_huff_decode(const JhDecodeWork &w, const JhGeom &g, hipStream_t s,
 	size_t lds = sizeof(JhHuffLut) * (size_t)w.max_luts;
 	dim3 gsub((w.max_subs + 255) / 256, w.nframes);
 	if (extra_sync_rounds == 0) {
+		JH_T_BEGIN(th, "k_huff_sync_intra", s);
 		hipLaunchKernelGGL(k_huff_sync_intra, gsub, dim3(256), lds, s, a);
+		JH_T_END(th, s);
 	}
 	const unsigned nbound = (w.max_subs + 255) / 256;
 	dim3 gb((nbound + 63) / 64, w.nframes);
+	JH_T_BEGIN(th, "k_huff_sync_inter", s);
 	for (int r = 0; r < JH_SYNC_ITERS; ++r) {
 		a.round = r;
 		hipLaunchKernelGGL(k_huff_sync_inter, gb, dim3(64), lds, s, a);
 	}
+	JH_T_END(th, s);
+	JH_T_BEGIN(th, "k_huff_scan", s);
 	hipLaunchKernelGGL(k_huff_scan, dim3(w.nframes), dim3(256), 0, s, a);
+	JH_T_END(th, s);
+	JH_T_BEGIN(th, "k_huff_write", s);
 	hipLaunchKernelGGL(k_huff_write, gsub, dim3(256), lds, s, a);
+	JH_T_END(th, s);
 	return hipGetLastError() == hipSuccess ? 0 : -1;
 }

@@ -144,13 +144,15 @@ __global__ __launch_bounds__(256) void k_enc_histogram(const EncArgs a)
 	}
 }
 
-int jh_launch_enc_histogram(const JhEncodeWork &w, const JhGeom &g, hipStream_t s)
+int jh_launch_enc_histogram(const JhEncodeWork &w, const JhGeom &g, hipStream_t s, const JhTimerHook *th)
 {
 	EncArgs a;
 	a.w = w;
 	a.g = g;
 	hipMemsetAsync(w.hist, 0, (size_t)w.nframes * 4 * 257 * sizeof(uint32_t), s);
+	JH_T_BEGIN(th, "k_enc_histogram", s);
 	hipLaunchKernelGGL(k_enc_histogram, dim3(w.nwg, w.nframes), dim3(256), 0, s, a);
+	JH_T_END(th, s);
 	return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -494,16 +496,28 @@ __global__ __launch_bounds__(256) void k_enc_stuff(const EncArgs a)
 	}
 }
 
-int jh_launch_enc_entropy(const JhEncodeWork &w, const JhGeom &g, hipStream_t s)
+int jh_launch_enc_entropy(const JhEncodeWork &w, const JhGeom &g, hipStream_t s, const JhTimerHook *th)
 {
 	EncArgs a;
 	a.w = w;
 	a.g = g;
+	JH_T_BEGIN(th, "k_enc_bitlen", s);
 	hipLaunchKernelGGL(k_enc_bitlen, dim3(w.nwg, w.nframes), dim3(256), 0, s, a);
+	JH_T_END(th, s);
+	JH_T_BEGIN(th, "k_enc_wg_scan", s);
 	hipLaunchKernelGGL(k_enc_wg_scan, dim3(w.nframes), dim3(256), 0, s, a);
+	JH_T_END(th, s);
+	JH_T_BEGIN(th, "k_enc_pack", s);
 	hipLaunchKernelGGL(k_enc_pack, dim3(w.nwg, w.nframes), dim3(256), 0, s, a);
+	JH_T_END(th, s);
+	JH_T_BEGIN(th, "k_enc_ffcount", s);
 	hipLaunchKernelGGL(k_enc_ffcount, dim3(w.nchunk, w.nframes), dim3(256), 0, s, a);
+	JH_T_END(th, s);
+	JH_T_BEGIN(th, "k_enc_ff_scan", s);
 	hipLaunchKernelGGL(k_enc_ff_scan, dim3(w.nframes), dim3(256), 0, s, a);
+	JH_T_END(th, s);
+	JH_T_BEGIN(th, "k_enc_stuff", s);
 	hipLaunchKernelGGL(k_enc_stuff, dim3(w.nchunk, w.nframes), dim3(256), 0, s, a);
+	JH_T_END(th, s);
 	return hipGetLastError() == hipSuccess ? 0 : -1;
 }

@@ -4,6 +4,15 @@
 #include <hip/hip_runtime.h>
 #include "common.hpp"
 
+// optional per-kernel timing hook (hipEvents recorded on the launch stream by api.hip)
+struct JhTimerHook {
+	void (*begin)(void *ctx, const char *name, hipStream_t s);
+	void (*end)(void *ctx, hipStream_t s);
+	void *ctx;
+};
+#define JH_T_BEGIN(hook, name, s) do { if ((hook) && (hook)->ctx) (hook)->begin((hook)->ctx, name, s); } while (0)
+#define JH_T_END(hook, s) do { if ((hook) && (hook)->ctx) (hook)->end((hook)->ctx, s); } while (0)
+
 // ---- per-frame descriptors shared by the entropy kernels ---------------------------------------
 
 struct JhDecFrame {               // written by the host in prepare()
@@ -54,8 +63,8 @@ struct JhDecodeWork {             // device pointers of one decoder batch
 	uint32_t max_luts;            // Huffman tables of the frame that uses most (LDS size)
 };
 
-int jh_launch_ecs_unstuff(const JhDecodeWork &w, hipStream_t s);
-int jh_launch_huff_decode(const JhDecodeWork &w, const JhGeom &g, hipStream_t s, int extra_sync_rounds);
+int jh_launch_ecs_unstuff(const JhDecodeWork &w, hipStream_t s, const JhTimerHook *th);
+int jh_launch_huff_decode(const JhDecodeWork &w, const JhGeom &g, hipStream_t s, int extra_sync_rounds, const JhTimerHook *th);
 
 int jh_launch_decode_pixels(const JhGeom &g, int nframes, const int16_t *coefs, const JhQuant *quant,
                             void *out, size_t frame_stride, hipStream_t stream);
@@ -96,5 +105,5 @@ struct JhEncodeWork {
 	int restart_interval;         // MCUs, 0 = none
 };
 
-int jh_launch_enc_histogram(const JhEncodeWork &w, const JhGeom &g, hipStream_t s);
-int jh_launch_enc_entropy(const JhEncodeWork &w, const JhGeom &g, hipStream_t s);
+int jh_launch_enc_histogram(const JhEncodeWork &w, const JhGeom &g, hipStream_t s, const JhTimerHook *th);
+int jh_launch_enc_entropy(const JhEncodeWork &w, const JhGeom &g, hipStream_t s, const JhTimerHook *th);
