@@ -147,7 +147,9 @@ struct jpeg_hip_decoder {
 	// device
 	uint8_t *d_raw = nullptr, *d_cs = nullptr;
 	uint32_t *d_seg = nullptr, *d_chunk_kept = nullptr, *d_chunk_rst = nullptr;
-	JhSubInfo *d_sub = nullptr;
+	JhSubInfo *d_sub = nullptr, *d_rec = nullptr;
+	uint32_t *d_meta = nullptr, *d_wg_exit = nullptr;
+	int *d_onfrom = nullptr;
 	JhSubStart *d_start = nullptr;
 	JhDecFrame *d_frames = nullptr;
 	JhDecState *d_state = nullptr;
@@ -166,7 +168,8 @@ struct jpeg_hip_decoder {
 	{
 		hipFree(d_raw); hipFree(d_cs); hipFree(d_seg); hipFree(d_chunk_kept); hipFree(d_chunk_rst);
 		hipFree(d_sub); hipFree(d_start); hipFree(d_frames); hipFree(d_state); hipFree(d_luts);
-		hipFree(d_quant); hipFree(d_coefs);
+		hipFree(d_quant); hipFree(d_coefs); hipFree(d_rec); hipFree(d_meta); hipFree(d_wg_exit); hipFree(d_onfrom);
+		d_rec = nullptr; d_meta = d_wg_exit = nullptr; d_onfrom = nullptr;
 		d_raw = d_cs = nullptr; d_seg = d_chunk_kept = d_chunk_rst = nullptr;
 		d_sub = nullptr; d_start = nullptr; d_frames = nullptr; d_state = nullptr; d_luts = nullptr;
 		d_quant = nullptr; d_coefs = nullptr;
@@ -228,7 +231,7 @@ extern "C" int jpeg_hip_decoder_prepare(jpeg_hip_decoder *dec, int nframes,
 	std::vector<JhHuffLut> luts;
 	std::vector<JhQuant> quant(nframes);
 	bool have_geom = false;
-	size_t raw_off = 0, cs_off = 0, seg_off = 0, chunk_off = 0, sub_off = 0;
+	size_t raw_off = 0, cs_off = 0, seg_off = 0, chunk_off = 0, sub_off = 0, wg_off = 0;
 	uint32_t max_chunks = 1, max_subs = 1, max_luts = 1;
 	std::vector<size_t> file_off(nframes);
 
@@ -273,6 +276,8 @@ extern "C" int jpeg_hip_decoder_prepare(jpeg_hip_decoder *dec, int nframes,
 			fr.nchunk = 0;
 			fr.lut_off = (uint32_t)luts.size();
 			fr.n_lut = 0;
+			fr.wg_off = (uint32_t)wg_off;
+			wg_off += 2;
 			cs_off += 64;
 			sub_off += 1;
 			seg_off += 4;
@@ -290,6 +295,8 @@ extern "C" int jpeg_hip_decoder_prepare(jpeg_hip_decoder *dec, int nframes,
 		const int Ri = h.g.Ri;
 		fr.seg_cap = (uint32_t)((Ri > 0 ? (h.g.nmcu + Ri - 1) / Ri : 1) + 64);
 		fr.chunk_off = (uint32_t)chunk_off;
+		fr.wg_off = (uint32_t)wg_off;
+		wg_off += fr.sub_cap / JH_SEQ_OWN + 2;
 		fr.nchunk = (uint32_t)((fr.raw_end + 4095) / 4096 - fr.raw_begin / 4096);
 		// Huffman tables used by this frame's scan -> LDS slots
 		int slot_of[2][4] = {{-1, -1, -1, -1}, {-1, -1, -1, -1}};
@@ -355,6 +362,13 @@ extern "C" int jpeg_hip_decoder_prepare(jpeg_hip_decoder *dec, int nframes,
 	HIPCHK(hipMalloc((void **)&dec->d_chunk_rst, dec->chunk_entries * 4));
 	HIPCHK(hipMalloc((void **)&dec->d_sub, dec->sub_entries * sizeof(JhSubInfo)));
 	HIPCHK(hipMalloc((void **)&dec->d_start, dec->sub_entries * sizeof(JhSubStart)));
+	HIPCHK(hipMalloc((void **)&dec->d_rec, dec->sub_entries * (JH_CHAIN_MAX + 1) * sizeof(JhSubInfo)));
+	HIPCHK(hipMalloc((void **)&dec->d_meta, dec->sub_entries * sizeof(uint32_t)));
+	HIPCHK(hipMalloc((void **)&dec->d_onfrom, dec->sub_entries * sizeof(int)));
+	HIPCHK(hipMalloc((void **)&dec->d_wg_exit, (wg_off + 4) * sizeof(uint32_t)));
+	HIPCHK(hipMemset(dec->d_meta, 0, dec->sub_entries * sizeof(uint32_t)));
+	HIPCHK(hipMemset(dec->d_onfrom, 0xff, dec->sub_entries * sizeof(int)));
+	HIPCHK(hipMemset(dec->d_wg_exit, 0xff, (wg_off + 4) * sizeof(uint32_t)));
 	HIPCHK(hipMalloc((void **)&dec->d_frames, nframes * sizeof(JhDecFrame)));
 	HIPCHK(hipMalloc((void **)&dec->d_state, nframes * sizeof(JhDecState)));
 	HIPCHK(hipMalloc((void **)&dec->d_luts, luts.size() * sizeof(JhHuffLut)));
@@ -379,6 +393,10 @@ extern "C" int jpeg_hip_decoder_prepare(jpeg_hip_decoder *dec, int nframes,
 	w.chunk_kept = dec->d_chunk_kept;
 	w.chunk_rst = dec->d_chunk_rst;
 	w.sub = dec->d_sub;
+	w.rec = dec->d_rec;
+	w.meta = dec->d_meta;
+	w.onfrom = dec->d_onfrom;
+	w.wg_exit = dec->d_wg_exit;
 	w.start = dec->d_start;
 	w.frames = dec->d_frames;
 	w.state = dec->d_state;
@@ -421,7 +439,9 @@ __global__ void k_dec_reset_rounds(JhDecState *st, int n)
 {
 	const int i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i < n) {
-		for (int r = 0; r <= JH_SYNC_ITERS; ++r) {
+		// a resync continues with full walks in rounds 1..JH_SYNC_ITERS: round 0 counts as "changed"
+		st[i].changed[0] = 1;
+		for (int r = 1; r <= JH_SYNC_ITERS; ++r) {
 			st[i].changed[r] = 0;
 		}
 	}

@@ -19,7 +19,9 @@
 #define JH_LUT_BITS 10                // fast table index width
 #define JH_SUBSEQ_BITS 1024           // bits per speculative sub-sequence (one thread each)
 #define JH_SUBSEQ_BYTES (JH_SUBSEQ_BITS / 8)
-#define JH_SYNC_ITERS 3               // inter-sequence synchronisation launches per run
+#define JH_SYNC_ITERS 3               // fix-up rounds launched per run (more only if the device asks)
+#define JH_CHAIN_MAX 16               // steps a speculative chain may walk before it is cut
+#define JH_SEQ_OWN (256 - JH_CHAIN_MAX)   // sub-sequences owned by one workgroup (the rest are ghosts)
 
 struct JhHuffLut {                    // one Huffman table, decoder view (Annex C / F.2.2.3)
 	uint16_t fast[1 << JH_LUT_BITS];  // (len << 8) | symbol for codes <= JH_LUT_BITS bits, else 0

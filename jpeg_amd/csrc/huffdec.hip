@@ -34,6 +34,7 @@
 #include <hip/hip_runtime.h>
 #include "common.hpp"
 #include "kernels.hpp"
+#include "huffcore.hpp"
 
 #define CHUNK_BYTES 4096              // raw bytes per workgroup in the un-stuffing kernels (256 x 16)
 
@@ -272,361 +273,6 @@ int jh_launch_ecs_unstuff(const JhDecodeWork &w, hipStream_t s, const JhTimerHoo
 	return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-// ===================================================================================== 2. decoding core
-
-struct DecTables {                    // workgroup-shared decode context (LDS)
-	uint8_t blk_dc[JH_MAX_MCU_BLOCKS], blk_ac[JH_MAX_MCU_BLOCKS], blk_comp[JH_MAX_MCU_BLOCKS];
-	uint8_t pad[2];
-};
-
-struct DecState {
-	uint32_t pos;                     // bit position of the next symbol
-	uint32_t seg;                     // restart segment that contains pos
-	int c, z;                         // block inside the MCU, next zig-zag index (0 = DC expected)
-	int reset;                        // a restart boundary was crossed
-	int nb;                           // blocks completed (partial MCUs before a boundary are discarded)
-	int dc[JH_MAX_COMP];              // DC difference sums since the last reset (WRITE: the predictors)
-};
-
-__device__ __forceinline__ unsigned long long pack_state(const DecState &s)
-{
-	return (unsigned long long)s.pos | ((unsigned long long)(s.c & 0xff) << 32) |
-	       ((unsigned long long)(s.z & 0xff) << 40) | ((unsigned long long)(s.reset & 1) << 48);
-}
-
-__device__ __forceinline__ uint32_t load_be32(const uint8_t *cs, uint32_t word)
-{
-	return __builtin_bswap32(reinterpret_cast<const uint32_t *>(cs)[word]);
-}
-
-// F.12: extend the sign of a cat-bit magnitude field (coeffs.c:33-48)
-__device__ __forceinline__ int extend(unsigned extra, int cat)
-{
-	return cat == 0 ? 0 : ((extra >> (cat - 1)) ? (int)extra : (int)extra - (1 << cat) + 1);
-}
-
-// Decode every symbol that STARTS before bit `stop`, beginning at st.pos.  WRITE selects the final
-// pass (coefficients stored, st.dc = predictors, blk = index of the block in progress).
-template <bool WRITE>
-__device__ __forceinline__ void decode_span(DecState &st, const uint32_t stop, const uint8_t *cs,
-                                            const uint32_t total_bits, const uint32_t *seg_start,
-                                            const uint32_t nseg, const JhHuffLut *luts,
-                                            const DecTables &tb, const int B,
-                                            int16_t *coefs, int blk, const int nblk)
-{
-	if (st.pos >= stop || st.pos >= total_bits) {
-		return;
-	}
-	uint32_t seg_end = min(seg_start[st.seg + 1] * 8u, total_bits);
-	uint32_t wpos = st.pos >> 5;
-	unsigned long long buf = ((unsigned long long)load_be32(cs, wpos) << 32) | load_be32(cs, wpos + 1);
-	buf <<= (st.pos & 31u);
-	int avail = 64 - (int)(st.pos & 31u);
-	wpos += 2;
-	uint32_t pos = st.pos;
-	int c = st.c, z = st.z;
-
-	while (pos < stop) {
-		if (avail < 32) {
-			buf |= (unsigned long long)load_be32(cs, wpos++) << (32 - avail);
-			avail += 32;
-		}
-		const JhHuffLut &lut = luts[z == 0 ? tb.blk_dc[c] : tb.blk_ac[c]];
-		unsigned e = lut.fast[(unsigned)(buf >> (64 - JH_LUT_BITS))];
-		int len = (int)(e >> 8);
-		unsigned sym = e & 0xffu;
-		bool invalid = false;
-		if (len == 0) {
-			// code longer than the fast table: canonical search on the left-aligned 16-bit window
-			const unsigned v = (unsigned)(buf >> 48);
-			len = JH_LUT_BITS + 1;
-#pragma unroll
-			for (int l = JH_LUT_BITS + 1; l < 16; ++l) {
-				len += v >= lut.limit[l] ? 1 : 0;
-			}
-			if (v >= lut.limit[16]) {
-				invalid = true;       // no code matches: the reference reads on to the end of the segment
-				sym = 0;
-			} else {
-				sym = lut.huffval[(lut.offs[len] + (int)(v >> (16 - len))) & 0xff];
-			}
-		}
-		const int cat = (int)(sym & 15u);
-		const int total = len + cat;
-		if (invalid || pos + (uint32_t)total > seg_end) {
-			// end of this restart segment (padding bits, truncated data or garbage): decoder.c:376-381.
-			// The MCU in progress is dropped (context->mblocks is not incremented), the next segment
-			// starts with block 0 / DC predictors 0 (decoder.c:369-373).
-			st.nb -= c;
-			if (WRITE) {
-				blk -= c;
-			}
-			c = 0;
-			z = 0;
-			st.reset = 1;
-#pragma unroll
-			for (int k = 0; k < JH_MAX_COMP; ++k) {
-				st.dc[k] = 0;
-			}
-			st.seg++;
-			if (st.seg >= nseg) {
-				pos = total_bits;
-				break;
-			}
-			pos = seg_end;
-			seg_end = min(seg_start[st.seg + 1] * 8u, total_bits);
-			wpos = pos >> 5;
-			buf = ((unsigned long long)load_be32(cs, wpos) << 32) | load_be32(cs, wpos + 1);
-			buf <<= (pos & 31u);
-			avail = 64 - (int)(pos & 31u);
-			wpos += 2;
-			continue;
-		}
-		const unsigned extra = cat ? (unsigned)((buf << len) >> (64 - cat)) : 0u;
-		buf <<= total;
-		avail -= total;
-		pos += (uint32_t)total;
-		if (z == 0) {
-			const int diff = extend(extra, cat);
-			const int comp = tb.blk_comp[c];
-			// dynamic index into a tiny array: keep it in registers with a select chain
-			int val = 0;
-#pragma unroll
-			for (int k = 0; k < JH_MAX_COMP; ++k) {
-				if (k == comp) {
-					st.dc[k] += diff;
-					val = st.dc[k];
-				}
-			}
-			if (WRITE && blk >= 0 && blk < nblk) {
-				coefs[(size_t)blk * 64] = (int16_t)val;      // DC un-prediction (decoder.c:351-355)
-			}
-			z = 1;
-		} else if (sym == 0) {
-			z = 64;                                            // EOB (coeffs.c:241-243)
-		} else {
-			z += (int)(sym >> 4);                              // zero run (coeffs.c:246)
-			if (WRITE && cat != 0 && z < 64 && blk >= 0 && blk < nblk) {
-				coefs[(size_t)blk * 64 + z] = (int16_t)extend(extra, cat);
-			}
-			z++;
-		}
-		if (z >= 64) {
-			z = 0;
-			c = (c + 1 == B) ? 0 : c + 1;
-			st.nb++;
-			if (WRITE) {
-				blk++;
-			}
-		}
-	}
-	st.pos = pos;
-	st.c = c;
-	st.z = z;
-}
-
-// segment that contains byte offset `byte` : largest k with seg_start[k] <= byte
-__device__ __forceinline__ uint32_t find_segment(const uint32_t *seg_start, uint32_t nseg, uint32_t byte)
-{
-	uint32_t lo = 0, hi = nseg;   // invariant: seg_start[lo] <= byte, answer in [lo, hi)
-	while (hi - lo > 1) {
-		const uint32_t mid = (lo + hi) >> 1;
-		if (seg_start[mid] <= byte) {
-			lo = mid;
-		} else {
-			hi = mid;
-		}
-	}
-	return lo;
-}
-
-__device__ __forceinline__ void load_tables(const JhDecodeWork &w, const JhDecFrame &fr, JhHuffLut *luts, DecTables *tb,
-                                            const JhGeom &g)
-{
-	const uint32_t *src = reinterpret_cast<const uint32_t *>(w.luts + fr.lut_off);
-	uint32_t *dst = reinterpret_cast<uint32_t *>(luts);
-	const int nw = (int)(fr.n_lut * sizeof(JhHuffLut) / 4);
-	for (int i = threadIdx.x; i < nw; i += blockDim.x) {
-		dst[i] = src[i];
-	}
-	if (threadIdx.x < JH_MAX_MCU_BLOCKS) {
-		// read through the global pointer: indexing the by-value copy would put it in scratch
-		const JhDecFrame *gf = w.frames + blockIdx.y;
-		tb->blk_dc[threadIdx.x] = gf->blk_dc[threadIdx.x];
-		tb->blk_ac[threadIdx.x] = gf->blk_ac[threadIdx.x];
-		tb->blk_comp[threadIdx.x] = (uint8_t)g.blk_comp[threadIdx.x];
-	}
-	__syncthreads();
-}
-
-__device__ __forceinline__ void store_info(JhSubInfo *dst, const DecState &s)
-{
-	JhSubInfo r;
-	r.state = pack_state(s);
-	r.seg = s.seg;
-	r.nb = s.nb;
-#pragma unroll
-	for (int k = 0; k < JH_MAX_COMP; ++k) {
-		r.dc[k] = s.dc[k];
-	}
-	*dst = r;
-}
-
-// chain state carried from one sub-sequence into the next: counters restart, position/phase stay
-__device__ __forceinline__ void next_subsequence(DecState &s)
-{
-	s.reset = 0;
-	s.nb = 0;
-#pragma unroll
-	for (int k = 0; k < JH_MAX_COMP; ++k) {
-		s.dc[k] = 0;
-	}
-}
-
-#define STATE_SYNC_MASK 0x0000ffffffffffffull      // pos, c, z (the reset flag is not part of the parse state)
-
-// ===================================================================================== 2. intra-sequence
-
-struct HuffArgs {
-	JhDecodeWork w;
-	JhGeom g;
-	int round;                         // synchronisation round (inter kernel)
-};
-
-__global__ __launch_bounds__(256) void k_huff_sync_intra(const HuffArgs a)
-{
-	extern __shared__ __align__(16) unsigned char smem[];
-	JhHuffLut *luts = reinterpret_cast<JhHuffLut *>(smem);
-	__shared__ DecTables tb;
-	__shared__ JhSubInfo sinfo[256];
-
-	const JhDecodeWork &w = a.w;
-	const int f = blockIdx.y;
-	const JhDecFrame fr = w.frames[f];
-	const JhDecState fs = w.state[f];
-	const uint32_t total_bits = fs.cs_len * 8u;
-	const uint32_t nsub = (total_bits + JH_SUBSEQ_BITS - 1) / JH_SUBSEQ_BITS;
-	const uint32_t t0 = blockIdx.x * 256u;
-	if (t0 >= nsub) {
-		return;
-	}
-	load_tables(w, fr, luts, &tb, a.g);
-
-	const uint8_t *cs = w.cs + fr.cs_off;
-	const uint32_t *seg_start = w.seg_start + fr.seg_off;
-	const uint32_t nseg = min(fs.nseg, fr.seg_cap - 1);
-	const int tid = threadIdx.x;
-	const uint32_t t = t0 + tid;
-	const bool active = t < nsub;
-
-	DecState st;
-	st.pos = t * JH_SUBSEQ_BITS;
-	st.c = 0;
-	st.z = 0;
-	st.reset = 0;
-	st.nb = 0;
-	st.seg = 0;
-#pragma unroll
-	for (int k = 0; k < JH_MAX_COMP; ++k) {
-		st.dc[k] = 0;
-	}
-	if (active) {
-		st.seg = nseg > 1 ? find_segment(seg_start, nseg, st.pos >> 3) : 0u;
-		decode_span<false>(st, (t + 1) * JH_SUBSEQ_BITS, cs, total_bits, seg_start, nseg, luts, tb, a.g.B, nullptr, 0, 0);
-		store_info(&sinfo[tid], st);
-	}
-	__syncthreads();
-
-	// chains: thread `tid` walks on into sub-sequences tid+1, tid+2, ... until its state matches
-	bool running = active;
-	for (int step = 1; step < 256; ++step) {
-		const int j = tid + step;
-		const bool work = running && j < 256 && (t0 + j) < nsub;
-		if (work) {
-			next_subsequence(st);
-			decode_span<false>(st, (t0 + j + 1) * JH_SUBSEQ_BITS, cs, total_bits, seg_start, nseg, luts, tb, a.g.B, nullptr, 0, 0);
-			const unsigned long long old = sinfo[j].state;
-			const unsigned long long now = pack_state(st);
-			store_info(&sinfo[j], st);
-			if (((old ^ now) & STATE_SYNC_MASK) == 0) {
-				running = false;       // in step with the chain that started later: everything after is shared
-			}
-		} else {
-			running = false;
-		}
-		if (!__syncthreads_or(running ? 1 : 0)) {
-			break;
-		}
-	}
-	if (active) {
-		w.sub[fr.sub_off + t] = sinfo[tid];
-	}
-}
-
-// ===================================================================================== 3. inter-sequence
-
-// One thread per workgroup boundary of the intra kernel.  Thread b (b >= 1) carries the exit state of
-// sub-sequence 256*b - 1 into the next sequence until it matches.  Launched JH_SYNC_ITERS times; a
-// round in which no state changed proves the fixed point (then the remaining rounds exit at once).
-__global__ __launch_bounds__(64) void k_huff_sync_inter(const HuffArgs a)
-{
-	extern __shared__ __align__(16) unsigned char smem[];
-	JhHuffLut *luts = reinterpret_cast<JhHuffLut *>(smem);
-	__shared__ DecTables tb;
-
-	const JhDecodeWork &w = a.w;
-	const int f = blockIdx.y;
-	const JhDecFrame fr = w.frames[f];
-	JhDecState &fs = w.state[f];
-	if (a.round > 0 && fs.changed[a.round - 1] == 0) {
-		if (threadIdx.x == 0 && blockIdx.x == 0) {
-			fs.changed[a.round] = 0;   // converged earlier: stay converged
-		}
-		return;
-	}
-	const uint32_t total_bits = fs.cs_len * 8u;
-	const uint32_t nsub = (total_bits + JH_SUBSEQ_BITS - 1) / JH_SUBSEQ_BITS;
-	const uint32_t nbound = (nsub + 255) / 256;       // sequences; boundaries are 1 .. nbound-1
-	if (blockIdx.x * 64u + 1 >= nbound) {
-		return;
-	}
-	load_tables(w, fr, luts, &tb, a.g);
-	const uint32_t b = blockIdx.x * 64u + threadIdx.x + 1;
-	if (b >= nbound) {
-		return;
-	}
-	const uint8_t *cs = w.cs + fr.cs_off;
-	const uint32_t *seg_start = w.seg_start + fr.seg_off;
-	const uint32_t nseg = min(fs.nseg, fr.seg_cap - 1);
-	JhSubInfo *sub = w.sub + fr.sub_off;
-
-	const JhSubInfo prev = sub[b * 256 - 1];
-	DecState st;
-	st.pos = (uint32_t)(prev.state & 0xffffffffu);
-	st.c = (int)((prev.state >> 32) & 0xff);
-	st.z = (int)((prev.state >> 40) & 0xff);
-	st.seg = prev.seg;
-	if (st.c >= a.g.B || st.z > 63 || st.seg >= nseg) {
-		return;                        // torn / stale read: a later round redoes this boundary
-	}
-	unsigned changed = 0;
-	const uint32_t jend = min(nsub, (b + 1) * 256);
-	for (uint32_t j = b * 256; j < jend; ++j) {
-		next_subsequence(st);
-		decode_span<false>(st, (j + 1) * JH_SUBSEQ_BITS, cs, total_bits, seg_start, nseg, luts, tb, a.g.B, nullptr, 0, 0);
-		const unsigned long long old = sub[j].state;
-		const unsigned long long now = pack_state(st);
-		store_info(&sub[j], st);
-		if (((old ^ now) & STATE_SYNC_MASK) == 0) {
-			break;
-		}
-		changed = 1;
-	}
-	if (changed) {
-		atomicAdd(&fs.changed[a.round], 1u);
-	}
-}
-
 // ===================================================================================== 4. scan
 
 // One workgroup per frame: exclusive prefix over the sub-sequence records.
@@ -744,10 +390,7 @@ __global__ __launch_bounds__(256) void k_huff_scan(const HuffArgs a)
 	if (tid == 0) {
 		fs.nblocks = (uint32_t)carry_nb;
 		// did the synchronisation reach its fixed point?
-		bool conv = false;
-		for (int r = 0; r < JH_SYNC_ITERS; ++r) {
-			conv = conv || fs.changed[r] == 0;
-		}
+		const bool conv = fs.changed[a.round] == 0;
 		if (!conv) {
 			fs.status |= JH_ST_NOT_CONVERGED;
 		} else {
@@ -810,19 +453,11 @@ int jh_launch_huff_decode(const JhDecodeWork &w, const JhGeom &g, hipStream_t s,
 	// one launch configuration for the batch: LDS for the largest table set of any frame
 	size_t lds = sizeof(JhHuffLut) * (size_t)w.max_luts;
 	dim3 gsub((w.max_subs + 255) / 256, w.nframes);
-	if (extra_sync_rounds == 0) {
-		JH_T_BEGIN(th, "k_huff_sync_intra", s);
-		hipLaunchKernelGGL(k_huff_sync_intra, gsub, dim3(256), lds, s, a);
-		JH_T_END(th, s);
+	if (jh_launch_huff_sync(w, g, s, extra_sync_rounds != 0, th)) {
+		return -1;
 	}
-	const unsigned nbound = (w.max_subs + 255) / 256;
-	dim3 gb((nbound + 63) / 64, w.nframes);
-	JH_T_BEGIN(th, "k_huff_sync_inter", s);
-	for (int r = 0; r < JH_SYNC_ITERS; ++r) {
-		a.round = r;
-		hipLaunchKernelGGL(k_huff_sync_inter, gb, dim3(64), lds, s, a);
-	}
-	JH_T_END(th, s);
+	// the scan checks the LAST fix-up round that ran: no exit changed there = fixed point
+	a.round = extra_sync_rounds != 0 ? JH_SYNC_ITERS : JH_SYNC_ITERS - 1;
 	JH_T_BEGIN(th, "k_huff_scan", s);
 	hipLaunchKernelGGL(k_huff_scan, dim3(w.nframes), dim3(256), 0, s, a);
 	JH_T_END(th, s);

@@ -27,6 +27,7 @@ struct JhDecFrame {               // written by the host in prepare()
 	uint32_t nchunk;
 	uint32_t lut_off;             // first JhHuffLut of this frame
 	uint32_t n_lut;
+	uint32_t wg_off;              // first entry of this frame in the workgroup exit table
 	uint8_t  blk_dc[JH_MAX_MCU_BLOCKS];   // lut slot per block of the MCU
 	uint8_t  blk_ac[JH_MAX_MCU_BLOCKS];
 };
@@ -51,7 +52,11 @@ struct JhDecodeWork {             // device pointers of one decoder batch
 	uint8_t *cs;                  // unstuffed streams
 	uint32_t *seg_start;          // byte offset of every restart segment inside cs (per frame slices)
 	uint32_t *chunk_kept, *chunk_rst;
-	JhSubInfo *sub;               // exit records
+	JhSubInfo *sub;               // TRUE exit record of every sub-sequence
+	JhSubInfo *rec;               // [sub-sequence t][step d <= JH_CHAIN_MAX]: chain t after sub-sequence t + d
+	uint32_t *meta;               // per chain: steps walked | (link distance << 8), 0 = cut
+	int *onfrom;                  // per chain: first sub-sequence it carries on its workgroup's canonical path, or -1
+	uint32_t *wg_exit;            // per workgroup: chain that carries the true parse into the next one
 	JhSubStart *start;            // entry records for the write pass
 	const JhDecFrame *frames;
 	JhDecState *state;
@@ -64,6 +69,7 @@ struct JhDecodeWork {             // device pointers of one decoder batch
 };
 
 int jh_launch_ecs_unstuff(const JhDecodeWork &w, hipStream_t s, const JhTimerHook *th);
+int jh_launch_huff_sync(const JhDecodeWork &w, const JhGeom &g, hipStream_t s, bool resync_only, const JhTimerHook *th);
 int jh_launch_huff_decode(const JhDecodeWork &w, const JhGeom &g, hipStream_t s, int extra_sync_rounds, const JhTimerHook *th);
 
 int jh_launch_decode_pixels(const JhGeom &g, int nframes, const int16_t *coefs, const JhQuant *quant,
