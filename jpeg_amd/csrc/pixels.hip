@@ -12,24 +12,34 @@
 //       ->  quantize_block (imgproc.c:21-30).
 //
 // Bit-exactness: this translation unit is compiled with -ffp-contract=off (no FMA), the DCT
-// uses the literal table T1 and the reference's summation order (s = 0.f; s += in*lut, index
-// ascending), colour maths runs in binary64 exactly where the reference's C expressions promote
-// to double, and fp32 division is hipcc's correctly rounded default.  MFMA is deliberately not
-// used: its fused accumulation cannot reproduce the reference's roundings.
+// uses the literal table T1 and the reference's summation order (index ascending), colour maths
+// runs in binary64 exactly where the reference's C expressions promote to double, and fp32
+// division is hipcc's correctly rounded default.  MFMA is deliberately not used: its fused
+// accumulation cannot reproduce the reference's roundings.
 //
-// Work decomposition (one workgroup = a run of G MCUs of one MCU row, 256-pixel wide tiles):
-//   phase 1  one thread per 8x8 block: the whole 2-D transform lives in VGPRs (64 values, all
-//            indices compile-time), coefficients come straight from HBM as 8 x 16-byte loads of the
-//            block's own 128-byte line.
-//   phase 2  one thread per 4 horizontally adjacent pixels: colour maths from the LDS tile and
-//            12-byte (u8 RGB) coalesced stores.
-// The kernels are VALU/HBM balanced (2048 unfused flops per 64 samples against 3-5 bytes/pixel).
+// The reference starts every 8-term sum with `s = 0.f; s += p0`.  `0.f + p0` differs from `p0`
+// only for p0 == -0.f, and a different SIGN OF ZERO in a partial sum can only change the sign of a
+// zero in the transform's result; the next consumer is either `+ shift` (decode) or
+// `(int)roundf(x / q)` (encode), both blind to it.  The sums here therefore start at p0.
+//
+// Work decomposition.  One workgroup = a run of G MCUs of one MCU row (about 96 blocks); the
+// tile lives in LDS as one float plane per component AT COMPONENT RESOLUTION, 8*V rows of
+// G*8*H (+4) floats.  All stages are "tasks" strided over the 256 threads:
+//   decode: A  (block, zig-zag octet): one coalesced 16-byte load, dequantise, scatter to raster
+//           B  (block, row)   : 1-D inverse transform of a row in 16 VGPRs (packed f32 maths)
+//           C  (block, column): 1-D inverse transform of a column, + level shift
+//           D  (row, 4 pixels): replication up-sampling, colour maths, 12/24-byte coalesced store
+//   encode: 1  (row group, 4 pixels): coalesced sample load, RGB -> YCbCr, box mean, level shift
+//           2/3 row / column forward transform, column pass quantises in place
+//           4  (block, zig-zag octet): gather, pack int16, one coalesced 16-byte store
+// 8 threads share a block, so a wave holds 16 live values per lane instead of 128: occupancy is
+// bounded by LDS (about 25 KB per workgroup), not by VGPRs.
 #include <hip/hip_runtime.h>
+#include <string.h>
 #include "common.hpp"
 #include "kernels.hpp"
 
-#define TILE_PITCH 72   // floats per block in LDS: 64 + 8 keeps the 8-wide row reads of neighbouring
-                        // blocks on different banks
+typedef float f2 __attribute__((ext_vector_type(2)));
 
 // zig-zag position -> raster index, usable in fully unrolled device code
 __device__ static constexpr int kZig[64] = {
@@ -38,66 +48,6 @@ __device__ static constexpr int kZig[64] = {
 	35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51,
 	58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63
 };
-
-// imgproc.c:104-115 / 130-149.  in-place 2-D inverse transform, rows first then columns.
-__device__ __forceinline__ void idct_block(float (&f)[64], const float (&L)[8][8])
-{
-	float t[64];
-#pragma unroll
-	for (int y = 0; y < 8; ++y) {
-#pragma unroll
-		for (int x = 0; x < 8; ++x) {
-			float s = 0.f;
-#pragma unroll
-			for (int u = 0; u < 8; ++u) {
-				s += f[y * 8 + u] * L[x][u];
-			}
-			t[y * 8 + x] = s;
-		}
-	}
-#pragma unroll
-	for (int x = 0; x < 8; ++x) {
-#pragma unroll
-		for (int y = 0; y < 8; ++y) {
-			float s = 0.f;
-#pragma unroll
-			for (int u = 0; u < 8; ++u) {
-				s += t[u * 8 + x] * L[y][u];
-			}
-			f[y * 8 + x] = s;
-		}
-	}
-}
-
-// imgproc.c:117-128 / 151-170.
-__device__ __forceinline__ void fdct_block(float (&f)[64], const float (&L)[8][8])
-{
-	float t[64];
-#pragma unroll
-	for (int y = 0; y < 8; ++y) {
-#pragma unroll
-		for (int u = 0; u < 8; ++u) {
-			float s = 0.f;
-#pragma unroll
-			for (int x = 0; x < 8; ++x) {
-				s += f[y * 8 + x] * L[x][u];
-			}
-			t[y * 8 + u] = s;
-		}
-	}
-#pragma unroll
-	for (int x = 0; x < 8; ++x) {
-#pragma unroll
-		for (int u = 0; u < 8; ++u) {
-			float s = 0.f;
-#pragma unroll
-			for (int y = 0; y < 8; ++y) {
-				s += t[y * 8 + x] * L[y][u];
-			}
-			f[u * 8 + x] = s;
-		}
-	}
-}
 
 // the literal table as compile-time constants (so that the unrolled products use inline literals)
 struct LutHolder {
@@ -111,6 +61,116 @@ __device__ __forceinline__ constexpr LutHolder make_lut()
 	}};
 }
 
+// One 1-D transform of 8 values held in registers, two outputs at a time (v_pk_mul_f32 /
+// v_pk_add_f32: unfused, each lane of the pair rounds like the scalar operation).
+//   INV:  idct1 (imgproc.c:104-115)  out[x] = sum_u in[u] * lut[x][u]
+//   !INV: fdct1 (imgproc.c:117-128)  out[u] = sum_x in[x] * lut[x][u]
+template <bool INV>
+__device__ __forceinline__ void dct1(const float (&in)[8], float (&out)[8])
+{
+	constexpr LutHolder LH = make_lut();
+#pragma unroll
+	for (int p = 0; p < 4; ++p) {
+		const int o0 = 2 * p, o1 = 2 * p + 1;
+		f2 acc = {0.f, 0.f};
+#pragma unroll
+		for (int i = 0; i < 8; ++i) {
+			const f2 c = INV ? f2{LH.v[o0][i], LH.v[o1][i]} : f2{LH.v[i][o0], LH.v[i][o1]};
+			const f2 prod = f2{in[i], in[i]} * c;
+			acc = i == 0 ? prod : acc + prod;
+		}
+		out[o0] = acc.x;
+		out[o1] = acc.y;
+	}
+}
+
+// ---- tile layout (host computed, shared by both kernels) -----------------------------------------
+struct TileLayout {
+	int G;                              // MCUs per workgroup
+	unsigned b_magic;                   // floor(2^32 / B) + 1: mcu = umulhi(block, b_magic)
+	int TW, TH;                         // tile size in frame pixels
+	unsigned qpr_magic;                 // floor(2^32 / (TW/4)) + 1
+	int base[JH_MAX_COMP], pitch[JH_MAX_COMP];          // component planes in LDS (floats)
+	int koff[JH_MAX_MCU_BLOCKS];        // block k of MCU 0: offset of its top-left sample
+	int kpitch[JH_MAX_MCU_BLOCKS];
+	int kmst[JH_MAX_MCU_BLOCKS];        // 8 * H of the block's component: column step per MCU
+	int ktq[JH_MAX_MCU_BLOCKS];         // quantisation table of the block's component
+	int sx_magic[JH_MAX_COMP], sy_magic[JH_MAX_COMP];   // 65536 / step + 1: c = (p * magic) >> 16
+	int lds_floats;
+};
+
+static void make_layout(const JhGeom &g, TileLayout *t)
+{
+	memset(t, 0, sizeof *t);
+	int G = 96 / g.B;
+	G = G < 1 ? 1 : G;
+	G = G > g.m_x ? g.m_x : G;
+	t->G = G;
+	t->b_magic = (unsigned)(0x100000000ull / (unsigned)g.B) + 1u;
+	t->TW = G * 8 * g.max_H;
+	t->TH = 8 * g.max_V;
+	t->qpr_magic = (unsigned)(0x100000000ull / (unsigned)(t->TW / 4)) + 1u;
+	int off = 0;
+	for (int c = 0; c < g.ncomp; ++c) {
+		t->base[c] = off;
+		t->pitch[c] = G * 8 * g.H[c] + 4;   // +4: rows start on different banks, stays 16-byte aligned
+		off += 8 * g.V[c] * t->pitch[c];
+		t->sx_magic[c] = 65536 / g.step_x[c] + 1;
+		t->sy_magic[c] = 65536 / g.step_y[c] + 1;
+	}
+	t->lds_floats = off;
+	for (int k = 0; k < g.B; ++k) {
+		const int c = g.blk_comp[k];
+		t->koff[k] = t->base[c] + g.blk_v[k] * 8 * t->pitch[c] + g.blk_h[k] * 8;
+		t->kpitch[k] = t->pitch[c];
+		t->kmst[k] = 8 * g.H[c];
+		t->ktq[k] = g.Tq[c] & 3;
+	}
+}
+
+struct BlockTask {
+	int addr;      // LDS float index of the block's top-left sample
+	int pitch;
+	int tq;
+};
+
+// per-k tables staged in LDS (indexed per lane)
+struct KTab {
+	int koff[JH_MAX_MCU_BLOCKS], kpitch[JH_MAX_MCU_BLOCKS], kmst[JH_MAX_MCU_BLOCKS], ktq[JH_MAX_MCU_BLOCKS];
+	uint32_t zig[8][2];                 // 8 raster indices (one byte each) per zig-zag octet
+};
+
+__device__ __forceinline__ void stage_ktab(KTab &kt, const TileLayout &L, int B, int tid)
+{
+	if (tid < B) {
+		kt.koff[tid] = L.koff[tid];
+		kt.kpitch[tid] = L.kpitch[tid];
+		kt.kmst[tid] = L.kmst[tid];
+		kt.ktq[tid] = L.ktq[tid];
+	}
+	if (tid >= 64 && tid < 72) {
+		const int j = tid - 64;
+		uint32_t lo = 0, hi = 0;
+		for (int e = 0; e < 4; ++e) {
+			lo |= (uint32_t)kZig[j * 8 + e] << (8 * e);
+			hi |= (uint32_t)kZig[j * 8 + 4 + e] << (8 * e);
+		}
+		kt.zig[j][0] = lo;
+		kt.zig[j][1] = hi;
+	}
+}
+
+__device__ __forceinline__ BlockTask block_task(const KTab &kt, const TileLayout &L, int B, int b)
+{
+	const int mcu = B == 1 ? b : (int)__umulhi((unsigned)b, L.b_magic);   // 2^32 / 1 does not fit
+	const int k = b - mcu * B;
+	BlockTask r;
+	r.pitch = kt.kpitch[k];
+	r.addr = kt.koff[k] + mcu * kt.kmst[k];
+	r.tq = kt.ktq[k];
+	return r;
+}
+
 // ================================================================================== decode
 
 struct DecPixArgs {
@@ -118,103 +178,153 @@ struct DecPixArgs {
 	const JhQuant *quant;      // [frame], zig-zag order
 	uint8_t *out;              // PPM/PGM bodies
 	size_t frame_stride;
-	int G;                     // MCUs per workgroup
+	TileLayout L;
 	JhGeom g;
 };
+
+// 4 horizontally adjacent frame pixels of component c: transform_components_to_frame (frame.c:63-76)
+// read backwards, frame(x, y) <- component(x / step_x, y / step_y)
+__device__ __forceinline__ void fetch4(const float *tile, const TileLayout &L, const JhGeom &g, int c,
+                                       int row, int px0, float (&s)[4])
+{
+	const int cy = (row * L.sy_magic[c]) >> 16;
+	const float *p = tile + L.base[c] + cy * L.pitch[c];
+	switch (g.step_x[c]) {
+	case 1: {
+		const float4 v = *reinterpret_cast<const float4 *>(p + px0);
+		s[0] = v.x; s[1] = v.y; s[2] = v.z; s[3] = v.w;
+		break;
+	}
+	case 2: {
+		const float2 v = *reinterpret_cast<const float2 *>(p + (px0 >> 1));
+		s[0] = s[1] = v.x;
+		s[2] = s[3] = v.y;
+		break;
+	}
+	case 4:
+		s[0] = s[1] = s[2] = s[3] = p[px0 >> 2];
+		break;
+	default:
+#pragma unroll
+		for (int i = 0; i < 4; ++i) {
+			s[i] = p[((px0 + i) * L.sx_magic[c]) >> 16];
+		}
+		break;
+	}
+}
 
 template <int NF>
 __global__ __launch_bounds__(256) void k_decode_pixels(const DecPixArgs a)
 {
 	extern __shared__ __align__(16) float tile[];
 	__shared__ uint16_t sq[4][64];
+	__shared__ KTab kt;
 
 	const JhGeom &g = a.g;
+	const TileLayout &L = a.L;
 	const int tid = threadIdx.x;
-	const int mx0 = blockIdx.x * a.G, my = blockIdx.y, f = blockIdx.z;
+	const int mx0 = blockIdx.x * L.G, my = blockIdx.y, f = blockIdx.z;
 	const int B = g.B;
-	const int nmcu_here = min(a.G, g.m_x - mx0);
+	const int nmcu_here = min(L.G, g.m_x - mx0);
+	const int ntask = nmcu_here * B * 8;
 
 	for (int i = tid; i < 4 * 64; i += 256) {
 		sq[i >> 6][i & 63] = a.quant[f].q[i >> 6][i & 63];
 	}
+	stage_ktab(kt, L, B, tid);
 	__syncthreads();
 
-	constexpr LutHolder LH = make_lut();
-	const float shiftf = (float)(1 << (g.P - 1));
-
-	// ---- phase 1: one thread per block ------------------------------------------------
-	for (int b = tid; b < nmcu_here * B; b += 256) {
-		const int mcu = b / B, k = b - mcu * B;
-		const int comp = g.blk_comp[k];
-		const int16_t *src = a.coefs + ((size_t)f * g.nblk + ((size_t)(my * g.m_x + mx0 + mcu) * B + k)) * 64;
-		const uint16_t *q = sq[g.Tq[comp] & 3];
-		float v[64];
-#pragma unroll
-		for (int j = 0; j < 8; ++j) {
-			const int4 w = reinterpret_cast<const int4 *>(src)[j];
+	// ---- A: (block, zig-zag octet): load, dequantise, scatter to raster order -------------------
+	{
+		const int4 *src = reinterpret_cast<const int4 *>(
+			a.coefs + ((size_t)f * g.nblk + (size_t)(my * g.m_x + mx0) * B) * 64);
+		for (int t = tid; t < ntask; t += 256) {
+			const int b = t >> 3, j = t & 7;
+			const BlockTask bt = block_task(kt, L, B, b);
+			const int4 w = src[t];
+			const uint32_t zlo = kt.zig[j][0], zhi = kt.zig[j][1];
+			const uint16_t *q = &sq[bt.tq][j * 8];
 			const int ws[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
-			for (int e = 0; e < 4; ++e) {
-				const int z0 = j * 8 + e * 2;
-				const int c0 = (int)(short)(ws[e] & 0xffff), c1 = ws[e] >> 16;
+			for (int e = 0; e < 8; ++e) {
+				const int cv = (e & 1) ? (ws[e >> 1] >> 16) : (int)(short)(ws[e >> 1] & 0xffff);
+				const int r = (int)(((e < 4 ? zlo : zhi) >> (8 * (e & 3))) & 0xff);
 				// dequantize_block: int32 product, then int -> float (imgproc.c:17)
-				v[kZig[z0]] = (float)(c0 * (int)q[z0]);
-				v[kZig[z0 + 1]] = (float)(c1 * (int)q[z0 + 1]);
+				tile[bt.addr + (r >> 3) * bt.pitch + (r & 7)] = (float)(cv * (int)q[e]);
 			}
-		}
-		idct_block(v, LH.v);
-		float4 *dst = reinterpret_cast<float4 *>(tile + b * TILE_PITCH);
-#pragma unroll
-		for (int j = 0; j < 16; ++j) {
-			// level shift: c += shift (imgproc.c:192-194)
-			dst[j] = make_float4(v[4 * j] + shiftf, v[4 * j + 1] + shiftf, v[4 * j + 2] + shiftf, v[4 * j + 3] + shiftf);
 		}
 	}
 	__syncthreads();
 
-	// ---- phase 2: one thread per 4 pixels ---------------------------------------------
-	const int TW = a.G * 8 * g.max_H, TH = 8 * g.max_V;
-	const int qpr = TW >> 2;                  // quads per tile row
+	// ---- B: (block, row): rows first (imgproc.c:134-140) ----------------------------------------
+	for (int t = tid; t < ntask; t += 256) {
+		const BlockTask bt = block_task(kt, L, B, t >> 3);
+		float4 *p = reinterpret_cast<float4 *>(tile + bt.addr + (t & 7) * bt.pitch);
+		const float4 v0 = p[0], v1 = p[1];
+		const float in[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+		float o[8];
+		dct1<true>(in, o);
+		p[0] = make_float4(o[0], o[1], o[2], o[3]);
+		p[1] = make_float4(o[4], o[5], o[6], o[7]);
+	}
+	__syncthreads();
+
+	// ---- C: (block, column): then columns (imgproc.c:142-148), level shift (imgproc.c:192-194) ---
+	{
+		const float shiftf = (float)(1 << (g.P - 1));
+		for (int t = tid; t < ntask; t += 256) {
+			const BlockTask bt = block_task(kt, L, B, t >> 3);
+			float *p = tile + bt.addr + (t & 7);
+			float in[8], o[8];
+#pragma unroll
+			for (int u = 0; u < 8; ++u) {
+				in[u] = p[u * bt.pitch];
+			}
+			dct1<true>(in, o);
+#pragma unroll
+			for (int y = 0; y < 8; ++y) {
+				p[y * bt.pitch] = o[y] + shiftf;
+			}
+		}
+	}
+	__syncthreads();
+
+	// ---- D: (row, 4 pixels): up-sampling, colour, rounding, store --------------------------------
+	const int qpr = L.TW >> 2;                // quads per tile row
 	const int X = g.X, Y = g.Y;
-	const int oc = NF == 1 ? 1 : 3;
+	constexpr int oc = NF == 1 ? 1 : 3;
 	const int maxval = (1 << g.P) - 1;
 	const int shift = 1 << (g.P - 1);
 	const int denom = 1 << g.P;
 	(void)denom;
+	(void)shift;
 	uint8_t *outf = a.out + (size_t)f * a.frame_stride;
 
-	for (int qd = tid; qd < TH * qpr; qd += 256) {
-		const int row = qd / qpr, px0 = (qd - row * qpr) * 4;
-		const int gy = my * TH + row, gx0 = mx0 * 8 * g.max_H + px0;
+	for (int qd = tid; qd < L.TH * qpr; qd += 256) {
+		const int row = (int)__umulhi((unsigned)qd, L.qpr_magic), px0 = (qd - row * qpr) * 4;
+		const int gy = my * L.TH + row, gx0 = mx0 * 8 * g.max_H + px0;
 		if (gy >= Y || gx0 >= X) {
 			continue;
 		}
-		int res[4][3];
+		float s[NF][4];
+#pragma unroll
+		for (int c = 0; c < NF; ++c) {
+			fetch4(tile, L, g, c, row, px0, s[c]);
+		}
+		int res[4 * oc];
 #pragma unroll
 		for (int i = 0; i < 4; ++i) {
-			const int px = px0 + i;
-			float s[NF];
-#pragma unroll
-			for (int c = 0; c < NF; ++c) {
-				// transform_components_to_frame: frame(x, y) <- component(x / step_x, y / step_y)
-				const int cx = px / g.step_x[c], cy = row / g.step_y[c];
-				const int wH = 8 * g.H[c];
-				const int mcu = cx / wH, cxi = cx - mcu * wH;
-				const int blk = mcu * B + g.comp_first[c] + (cy >> 3) * g.H[c] + (cxi >> 3);
-				s[c] = tile[blk * TILE_PITCH + (cy & 7) * 8 + (cxi & 7)];
-			}
-			float o[3];
+			float o[oc];
 			if constexpr (NF == 1) {
-				o[0] = s[0];
-				o[1] = o[2] = 0.f;
+				o[0] = s[0][i];
 			} else {
 				// frame.c:204-206 / 226-228: (C - shift) is a float subtract, the rest is double
-				const float Yl = s[0], Cb = s[1], Cr = s[2];
+				const float Yl = s[0][i], Cb = s[1][i], Cr = s[2][i];
 				const float r_ = Yl + 1.402 * (Cr - shift);
 				const float g_ = Yl - 0.34414 * (Cb - shift) - 0.71414 * (Cr - shift);
 				const float b_ = Yl + 1.772 * (Cb - shift);
 				if constexpr (NF == 4) {
-					const float K = s[NF - 1];
+					const float K = s[NF - 1][i];
 					o[0] = K - (r_ * K) / denom;       // frame.c:208-210 (all float)
 					o[1] = K - (g_ * K) / denom;
 					o[2] = K - (b_ * K) / denom;
@@ -225,46 +335,39 @@ __global__ __launch_bounds__(256) void k_decode_pixels(const DecPixArgs a)
 				}
 			}
 #pragma unroll
-			for (int c = 0; c < 3; ++c) {
+			for (int c = 0; c < oc; ++c) {
 				const int iv = (int)roundf(o[c]);               // frame.c:375-376
-				res[i][c] = min(max(iv, 0), maxval);
+				res[i * oc + c] = min(max(iv, 0), maxval);
 			}
 		}
 		const int npx = min(4, X - gx0);
 		if (g.sample_bytes == 1) {
 			uint8_t *p = outf + ((size_t)gy * X + gx0) * oc;
-			if (oc == 3) {
-				if (npx == 4 && ((reinterpret_cast<uintptr_t>(p) & 3) == 0)) {
-					uint32_t w0 = res[0][0] | (res[0][1] << 8) | (res[0][2] << 16) | (res[1][0] << 24);
-					uint32_t w1 = res[1][1] | (res[1][2] << 8) | (res[2][0] << 16) | (res[2][1] << 24);
-					uint32_t w2 = res[2][2] | (res[3][0] << 8) | (res[3][1] << 16) | (res[3][2] << 24);
-					uint32_t *pw = reinterpret_cast<uint32_t *>(p);
-					pw[0] = w0;
-					pw[1] = w1;
-					pw[2] = w2;
-				} else {
-					for (int i = 0; i < npx; ++i) {
-						p[3 * i] = (uint8_t)res[i][0];
-						p[3 * i + 1] = (uint8_t)res[i][1];
-						p[3 * i + 2] = (uint8_t)res[i][2];
-					}
+			if (npx == 4 && ((reinterpret_cast<uintptr_t>(p) & 3) == 0)) {
+				uint32_t *pw = reinterpret_cast<uint32_t *>(p);
+#pragma unroll
+				for (int wd = 0; wd < oc; ++wd) {
+					pw[wd] = res[4 * wd] | (res[4 * wd + 1] << 8) | (res[4 * wd + 2] << 16) | (res[4 * wd + 3] << 24);
 				}
 			} else {
-				if (npx == 4 && ((reinterpret_cast<uintptr_t>(p) & 3) == 0)) {
-					*reinterpret_cast<uint32_t *>(p) = res[0][0] | (res[1][0] << 8) | (res[2][0] << 16) | (res[3][0] << 24);
-				} else {
-					for (int i = 0; i < npx; ++i) {
-						p[i] = (uint8_t)res[i][0];
-					}
+				for (int i = 0; i < npx * oc; ++i) {
+					p[i] = (uint8_t)res[i];
 				}
 			}
 		} else {
 			// big-endian 16-bit samples (htons, frame.c:386)
 			uint8_t *p = outf + ((size_t)gy * X + gx0) * oc * 2;
-			for (int i = 0; i < npx; ++i) {
-				for (int c = 0; c < oc; ++c) {
-					p[(i * oc + c) * 2] = (uint8_t)(res[i][c] >> 8);
-					p[(i * oc + c) * 2 + 1] = (uint8_t)res[i][c];
+			if (npx == 4 && ((reinterpret_cast<uintptr_t>(p) & 3) == 0)) {
+				uint32_t *pw = reinterpret_cast<uint32_t *>(p);
+#pragma unroll
+				for (int wd = 0; wd < 2 * oc; ++wd) {
+					const int s0 = res[2 * wd], s1 = res[2 * wd + 1];
+					pw[wd] = (s0 >> 8) | ((s0 & 0xff) << 8) | ((s1 >> 8) << 16) | ((s1 & 0xff) << 24);
+				}
+			} else {
+				for (int i = 0; i < npx * oc; ++i) {
+					p[2 * i] = (uint8_t)(res[i] >> 8);
+					p[2 * i + 1] = (uint8_t)res[i];
 				}
 			}
 		}
@@ -279,10 +382,10 @@ int jh_launch_decode_pixels(const JhGeom &g, int nframes, const int16_t *coefs, 
 	a.quant = quant;
 	a.out = (uint8_t *)out;
 	a.frame_stride = frame_stride;
-	a.G = 32 / g.max_H > 0 ? 32 / g.max_H : 1;
+	make_layout(g, &a.L);
 	a.g = g;
-	dim3 grid((g.m_x + a.G - 1) / a.G, g.m_y, nframes);
-	size_t lds = (size_t)a.G * g.B * TILE_PITCH * sizeof(float);
+	dim3 grid((g.m_x + a.L.G - 1) / a.L.G, g.m_y, nframes);
+	const size_t lds = (size_t)a.L.lds_floats * sizeof(float);
 	switch (g.Nf) {
 	case 1:
 		hipLaunchKernelGGL(k_decode_pixels<1>, grid, dim3(256), lds, stream, a);
@@ -306,114 +409,203 @@ struct EncPixArgs {
 	size_t frame_stride;
 	const JhQuant *quant;      // [frame] RASTER order here (divisors are applied in raster order)
 	int16_t *coefs;            // [frame][nblk][64] zig-zag
-	int G;
+	TileLayout L;
 	JhGeom g;
 };
 
+// 4 horizontally adjacent samples-tuples of the input body as floats: read_frame_body (frame.c:295-345)
+// incl. its padding rule (last column / last row replicated).  Fast path: whole dwords.
 template <int NF>
+__device__ __forceinline__ void load4(const uint8_t *inf, int X, int Y, int sb, int gx0, int gy, float (&s)[4][NF])
+{
+	if (gx0 + 3 < X && gy < Y) {
+		const uint8_t *p = inf + ((size_t)gy * X + gx0) * NF * sb;
+		if ((reinterpret_cast<uintptr_t>(p) & 3) == 0) {
+			const uint32_t *pw = reinterpret_cast<const uint32_t *>(p);
+			if (sb == 1) {
+				uint32_t w[NF];
+#pragma unroll
+				for (int i = 0; i < NF; ++i) {
+					w[i] = pw[i];
+				}
+#pragma unroll
+				for (int n = 0; n < 4 * NF; ++n) {
+					s[n / NF][n % NF] = (float)((w[n >> 2] >> (8 * (n & 3))) & 0xff);
+				}
+			} else {
+				uint32_t w[2 * NF];
+#pragma unroll
+				for (int i = 0; i < 2 * NF; ++i) {
+					w[i] = pw[i];
+				}
+#pragma unroll
+				for (int n = 0; n < 4 * NF; ++n) {
+					const uint32_t h = (w[n >> 1] >> (16 * (n & 1))) & 0xffff;
+					s[n / NF][n % NF] = (float)(((h & 0xff) << 8) | (h >> 8));   // ntohs (frame.c:321)
+				}
+			}
+			return;
+		}
+	}
+	const int sy = min(gy, Y - 1);
+#pragma unroll
+	for (int i = 0; i < 4; ++i) {
+		const int sx = min(gx0 + i, X - 1);
+		const uint8_t *p = inf + ((size_t)sy * X + sx) * NF * sb;
+#pragma unroll
+		for (int c = 0; c < NF; ++c) {
+			s[i][c] = sb == 1 ? (float)p[c] : (float)((p[2 * c] << 8) | p[2 * c + 1]);
+		}
+	}
+}
+
+// NF = 1: one plane, no sub-sampling.  NF = 3: luma at full resolution, both chroma planes
+// down-sampled SX x SY (what read_image() sets up: luma H x V, chroma 1 x 1; encoder.c:109-146).
+template <int NF, int SX, int SY>
 __global__ __launch_bounds__(256) void k_encode_pixels(const EncPixArgs a)
 {
-	extern __shared__ __align__(16) float plane[];   // NF planes of TH x TWP floats (full resolution)
-	__shared__ uint16_t sq[4][64];
+	extern __shared__ __align__(16) float tile[];
+	__shared__ float sqf[4][64];
+	__shared__ KTab kt;
 
 	const JhGeom &g = a.g;
+	const TileLayout &L = a.L;
 	const int tid = threadIdx.x;
-	const int mx0 = blockIdx.x * a.G, my = blockIdx.y, f = blockIdx.z;
+	const int mx0 = blockIdx.x * L.G, my = blockIdx.y, f = blockIdx.z;
 	const int B = g.B;
-	const int nmcu_here = min(a.G, g.m_x - mx0);
-	const int TW = a.G * 8 * g.max_H, TH = 8 * g.max_V;
-	const int TWP = TW + 1;                          // odd pitch: column walks of 8x8 gathers spread over banks
+	const int nmcu_here = min(L.G, g.m_x - mx0);
+	const int ntask = nmcu_here * B * 8;
 	const int X = g.X, Y = g.Y;
 	const int shift = 1 << (g.P - 1);
+	const float shiftf = (float)shift;
 	const uint8_t *inf = a.in + (size_t)f * a.frame_stride;
 
 	for (int i = tid; i < 4 * 64; i += 256) {
-		sq[i >> 6][i & 63] = a.quant[f].q[i >> 6][i & 63];
+		sqf[i >> 6][i & 63] = (float)a.quant[f].q[i >> 6][i & 63];
 	}
+	stage_ktab(kt, L, B, tid);
 
-	// ---- phase 1: samples -> float, replicate edges, RGB -> YCbCr -----------------------
-	const int wpx = nmcu_here * 8 * g.max_H;
-	for (int i = tid; i < TH * wpx; i += 256) {
-		const int row = i / wpx, px = i - row * wpx;
-		const int gx = mx0 * 8 * g.max_H + px, gy = my * TH + row;
-		// read_frame_body: padding copies the last column / last row (frame.c:309-345)
-		const int sx = min(gx, X - 1), sy = min(gy, Y - 1);
-		float s[NF];
-		if (g.sample_bytes == 1) {
-			const uint8_t *p = inf + ((size_t)sy * X + sx) * NF;
-#pragma unroll
-			for (int c = 0; c < NF; ++c) {
-				s[c] = (float)p[c];
+	// ---- 1: (row group, 4 pixels): samples -> float, RGB -> YCbCr, box mean, level shift --------
+	{
+		const int qpr = L.TW >> 2;
+		const int wpx = nmcu_here * 8 * g.max_H;
+		const int ngroups = (L.TH / SY) * qpr;
+		for (int qd = tid; qd < ngroups; qd += 256) {
+			const int rg = (int)__umulhi((unsigned)qd, L.qpr_magic), px0 = (qd - rg * qpr) * 4;
+			if (px0 >= wpx) {
+				continue;
 			}
-		} else {
-			const uint8_t *p = inf + ((size_t)sy * X + sx) * NF * 2;
+			const int gx0 = mx0 * 8 * g.max_H + px0;
+			float ch[2][SY][4];
 #pragma unroll
-			for (int c = 0; c < NF; ++c) {
-				s[c] = (float)((p[2 * c] << 8) | p[2 * c + 1]);      // ntohs (frame.c:321)
+			for (int sy = 0; sy < SY; ++sy) {
+				const int row = rg * SY + sy, gy = my * L.TH + row;
+				float s[4][NF];
+				load4<NF>(inf, X, Y, g.sample_bytes, gx0, gy, s);
+				float y4[4];
+#pragma unroll
+				for (int i = 0; i < 4; ++i) {
+					if constexpr (NF == 3) {
+						if (gx0 + i < X && gy < Y) {
+							// frame_to_ycc (frame.c:168-170): double arithmetic, left to right, rounded to
+							// float.  Padding pixels keep their raw RGB values (loops stop at X, Y: quirk Q7).
+							const float R = s[i][0], G_ = s[i][1], B_ = s[i][2];
+							const float Yl = 0.299 * R + 0.587 * G_ + 0.114 * B_;
+							const float Cb = - 0.1687 * R - 0.3313 * G_ + 0.5 * B_ + shift;
+							const float Cr = 0.5 * R - 0.4187 * G_ - 0.0813 * B_ + shift;
+							s[i][0] = Yl;
+							s[i][1] = Cb;
+							s[i][2] = Cr;
+						}
+						ch[0][sy][i] = s[i][1];
+						ch[1][sy][i] = s[i][2];
+					}
+					// luma: step 1 x 1: px = 0.f + s; px /= 1 (frame.c:114-123); then the level shift
+					// of forward_dct (imgproc.c:220-222)
+					y4[i] = (0.f + s[i][0]) - shiftf;
+				}
+				*reinterpret_cast<float4 *>(tile + L.base[0] + row * L.pitch[0] + px0) =
+					make_float4(y4[0], y4[1], y4[2], y4[3]);
 			}
-		}
-		if constexpr (NF == 3) if (gx < X && gy < Y) {
-			// frame_to_ycc (frame.c:168-170): double arithmetic, left to right, rounded to float.
-			// Padding pixels keep their raw RGB values (loops stop at X, Y: quirk Q7).
-			const float R = s[0], G_ = s[1], B_ = s[2];
-			const float Yl = 0.299 * R + 0.587 * G_ + 0.114 * B_;
-			const float Cb = - 0.1687 * R - 0.3313 * G_ + 0.5 * B_ + shift;
-			const float Cr = 0.5 * R - 0.4187 * G_ - 0.0813 * B_ + shift;
-			s[0] = Yl;
-			s[1] = Cb;
-			s[2] = Cr;
-		}
+			if constexpr (NF == 3) {
 #pragma unroll
-		for (int c = 0; c < NF; ++c) {
-			plane[(c * TH + row) * TWP + px] = s[c];
+				for (int c = 0; c < 2; ++c) {
+					float o[4 / SX];
+#pragma unroll
+					for (int ox = 0; ox < 4 / SX; ++ox) {
+						// transform_frame_to_components (frame.c:114-123): px = 0.f; += (yy outer, xx inner); /= area
+						float px = 0.f;
+#pragma unroll
+						for (int yy = 0; yy < SY; ++yy) {
+#pragma unroll
+							for (int xx = 0; xx < SX; ++xx) {
+								px += ch[c][yy][ox * SX + xx];
+							}
+						}
+						px /= (float)(SY * SX);
+						o[ox] = px - shiftf;
+					}
+					float *dst = tile + L.base[c + 1] + rg * L.pitch[c + 1] + px0 / SX;
+					if constexpr (SX == 1) {
+						*reinterpret_cast<float4 *>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+					} else {
+						*reinterpret_cast<float2 *>(dst) = make_float2(o[0], o[1]);
+					}
+				}
+			}
 		}
 	}
 	__syncthreads();
 
-	constexpr LutHolder LH = make_lut();
-	const float shiftf = (float)shift;
+	// ---- 2: (block, row): rows first (imgproc.c:155-161) -----------------------------------------
+	for (int t = tid; t < ntask; t += 256) {
+		const BlockTask bt = block_task(kt, L, B, t >> 3);
+		float4 *p = reinterpret_cast<float4 *>(tile + bt.addr + (t & 7) * bt.pitch);
+		const float4 v0 = p[0], v1 = p[1];
+		const float in[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+		float o[8];
+		dct1<false>(in, o);
+		p[0] = make_float4(o[0], o[1], o[2], o[3]);
+		p[1] = make_float4(o[4], o[5], o[6], o[7]);
+	}
+	__syncthreads();
 
-	// ---- phase 2: one thread per block: box mean, level shift, FDCT, quantise ----------------
-	for (int b = tid; b < nmcu_here * B; b += 256) {
-		const int mcu = b / B, k = b - mcu * B;
-		const int comp = g.blk_comp[k];
-		const int stx = g.step_x[comp], sty = g.step_y[comp];
-		// top-left of the block in full-resolution tile coordinates
-		const int x0 = (mcu * 8 * g.H[comp] + g.blk_h[k] * 8) * stx;
-		const int y0 = (g.blk_v[k] * 8) * sty;
-		const float *pl = plane + comp * TH * TWP;
-		const float area = (float)(sty * stx);
-		float v[64];
+	// ---- 3: (block, column): columns (imgproc.c:163-169), then quantize_block (imgproc.c:28) -------
+	for (int t = tid; t < ntask; t += 256) {
+		const BlockTask bt = block_task(kt, L, B, t >> 3);
+		const int x = t & 7;
+		float *p = tile + bt.addr + x;
+		const float *q = &sqf[bt.tq][x];
+		float in[8], o[8];
 #pragma unroll
-		for (int yy = 0; yy < 8; ++yy) {
-#pragma unroll
-			for (int xx = 0; xx < 8; ++xx) {
-				// transform_frame_to_components (frame.c:114-123): px = 0.f; += rows then columns; /= area
-				float px = 0.f;
-				for (int sy = 0; sy < sty; ++sy) {
-					for (int sx = 0; sx < stx; ++sx) {
-						px += pl[(y0 + yy * sty + sy) * TWP + x0 + xx * stx + sx];
-					}
-				}
-				px /= area;
-				v[yy * 8 + xx] = px - shiftf;                   // forward_dct level shift (imgproc.c:220-222)
-			}
+		for (int y = 0; y < 8; ++y) {
+			in[y] = p[y * bt.pitch];
 		}
-		fdct_block(v, LH.v);
-		const uint16_t *q = sq[g.Tq[comp] & 3];
-		int16_t *dst = a.coefs + ((size_t)f * g.nblk + ((size_t)(my * g.m_x + mx0 + mcu) * B + k)) * 64;
+		dct1<false>(in, o);
 #pragma unroll
-		for (int j = 0; j < 8; ++j) {
-			int w[4];
+		for (int u = 0; u < 8; ++u) {
+			// IEEE divide, round half away from zero
+			p[u * bt.pitch] = __int_as_float((int)roundf(o[u] / q[u * 8]));
+		}
+	}
+	__syncthreads();
+
+	// ---- 4: (block, zig-zag octet): gather, pack, store -------------------------------------------
+	{
+		int4 *dst = reinterpret_cast<int4 *>(
+			a.coefs + ((size_t)f * g.nblk + (size_t)(my * g.m_x + mx0) * B) * 64);
+		for (int t = tid; t < ntask; t += 256) {
+			const int j = t & 7;
+			const BlockTask bt = block_task(kt, L, B, t >> 3);
+			const uint32_t zlo = kt.zig[j][0], zhi = kt.zig[j][1];
+			int cv[8];
 #pragma unroll
-			for (int e = 0; e < 4; ++e) {
-				const int z0 = j * 8 + e * 2;
-				// quantize_block (imgproc.c:28): IEEE divide, round half away from zero
-				const int c0 = (int)roundf(v[kZig[z0]] / (float)q[kZig[z0]]);
-				const int c1 = (int)roundf(v[kZig[z0 + 1]] / (float)q[kZig[z0 + 1]]);
-				w[e] = (c0 & 0xffff) | (c1 << 16);
+			for (int e = 0; e < 8; ++e) {
+				const int r = (int)(((e < 4 ? zlo : zhi) >> (8 * (e & 3))) & 0xff);
+				cv[e] = __float_as_int(tile[bt.addr + (r >> 3) * bt.pitch + (r & 7)]);
 			}
-			reinterpret_cast<int4 *>(dst)[j] = make_int4(w[0], w[1], w[2], w[3]);
+			dst[t] = make_int4((cv[0] & 0xffff) | (cv[1] << 16), (cv[2] & 0xffff) | (cv[3] << 16),
+			                   (cv[4] & 0xffff) | (cv[5] << 16), (cv[6] & 0xffff) | (cv[7] << 16));
 		}
 	}
 }
@@ -426,20 +618,31 @@ int jh_launch_encode_pixels(const JhGeom &g, int nframes, const void *in, size_t
 	a.frame_stride = frame_stride;
 	a.quant = quant_raster;
 	a.coefs = coefs;
-	a.G = 16 / g.max_H > 0 ? 16 / g.max_H : 1;
+	make_layout(g, &a.L);
 	a.g = g;
-	dim3 grid((g.m_x + a.G - 1) / a.G, g.m_y, nframes);
-	const int TW = a.G * 8 * g.max_H, TH = 8 * g.max_V;
-	size_t lds = (size_t)g.Nf * TH * (TW + 1) * sizeof(float);
-	switch (g.Nf) {
-	case 1:
-		hipLaunchKernelGGL(k_encode_pixels<1>, grid, dim3(256), lds, stream, a);
-		break;
-	case 3:
-		hipLaunchKernelGGL(k_encode_pixels<3>, grid, dim3(256), lds, stream, a);
-		break;
-	default:
-		return -1;
+	dim3 grid((g.m_x + a.L.G - 1) / a.L.G, g.m_y, nframes);
+	const size_t lds = (size_t)a.L.lds_floats * sizeof(float);
+	if (g.Nf == 1) {
+		hipLaunchKernelGGL((k_encode_pixels<1, 1, 1>), grid, dim3(256), lds, stream, a);
+	} else if (g.Nf == 3 && g.step_x[0] == 1 && g.step_y[0] == 1 && g.step_x[1] == g.max_H && g.step_y[1] == g.max_V &&
+	           g.step_x[2] == g.max_H && g.step_y[2] == g.max_V && g.max_H <= 2 && g.max_V <= 2) {
+		const int code = g.max_H * 10 + g.max_V;
+		switch (code) {
+		case 11:
+			hipLaunchKernelGGL((k_encode_pixels<3, 1, 1>), grid, dim3(256), lds, stream, a);
+			break;
+		case 21:
+			hipLaunchKernelGGL((k_encode_pixels<3, 2, 1>), grid, dim3(256), lds, stream, a);
+			break;
+		case 12:
+			hipLaunchKernelGGL((k_encode_pixels<3, 1, 2>), grid, dim3(256), lds, stream, a);
+			break;
+		default:
+			hipLaunchKernelGGL((k_encode_pixels<3, 2, 2>), grid, dim3(256), lds, stream, a);
+			break;
+		}
+	} else {
+		return -1;   // jpeg_hip_encoder_configure() admits nothing else (encoder.c:123-124)
 	}
 	return hipGetLastError() == hipSuccess ? 0 : -1;
 }
