@@ -288,7 +288,7 @@ extern "C" int jpeg_hip_decoder_prepare(jpeg_hip_decoder *dec, int nframes,
 		fr.raw_end = (uint32_t)(raw_off + flen);
 		const size_t ecs = flen - h.ecs_offset;
 		fr.cs_off = (uint32_t)cs_off;
-		const size_t cs_cap = align_up(ecs + 32, 64);
+		const size_t cs_cap = align_up(ecs + 32 + 256, 64);      // staging reads a few words past the end
 		fr.sub_off = (uint32_t)sub_off;
 		fr.sub_cap = (uint32_t)(cs_cap / JH_SUBSEQ_BYTES + 2);
 		fr.seg_off = (uint32_t)seg_off;
@@ -306,7 +306,7 @@ extern "C" int jpeg_hip_decoder_prepare(jpeg_hip_decoder *dec, int nframes,
 			for (int tc = 0; tc < 2 && !err; ++tc) {
 				if (slot_of[tc][ids[tc]] < 0) {
 					JhHuffLut l;
-					err = jh_build_declut(&h.ht[tc][ids[tc]], &l);
+					err = jh_build_declut(&h.ht[tc][ids[tc]], tc, &l);
 					slot_of[tc][ids[tc]] = (int)fr.n_lut++;
 					luts.push_back(l);
 				}

@@ -115,28 +115,55 @@ static int canon_codes(const JhHuffSpec *s, CanonCodes *c)
 	return RET_SUCCESS;
 }
 
-int jh_build_declut(const JhHuffSpec *s, JhHuffLut *lut)
+int jh_build_declut(const JhHuffSpec *s, int tc, JhHuffLut *lut)
 {
 	CanonCodes c;
 	int err = canon_codes(s, &c);
 	if (err) {
 		return err;
 	}
+	static_assert(sizeof(JhHuffLut) % 16 == 0, "table offsets are kept in units of 16 bytes");
 	memset(lut, 0, sizeof *lut);
 	memcpy(lut->huffval, s->V, 256);
-	// fast table: every JH_LUT_BITS-bit window that starts with a code of <= JH_LUT_BITS bits.
 	// query_code() (huffman.c:193-225) returns the FIRST table entry that matches; canonical
 	// codes are prefix-free, so filling in table order without overwriting reproduces that.
+	int nsub = 0;
 	for (int p = 0; p < c.n; ++p) {
 		const int len = c.size[p];
-		if (len > JH_LUT_BITS) {
+		// (code length + category, zero run, category); EOB of an AC table = run 63 (huffcore.hpp)
+		const unsigned sym = s->V[p];
+		const unsigned cat = sym & 15u;
+		const unsigned run = (tc == 1 && sym == 0) ? 63u : (sym >> 4);
+		const uint16_t entry = (uint16_t)(((len + cat) << 10) | (run << 4) | cat);
+		if (len <= JH_LUT_BITS) {
+			// every JH_LUT_BITS-bit window that starts with this code
+			const unsigned first = (unsigned)c.code[p] << (JH_LUT_BITS - len);
+			const unsigned count = 1u << (JH_LUT_BITS - len);
+			for (unsigned i = 0; i < count && first + i < (1u << JH_LUT_BITS); ++i) {
+				if (lut->fast[first + i] == 0) {
+					lut->fast[first + i] = entry;
+				}
+			}
 			continue;
 		}
-		const unsigned first = (unsigned)c.code[p] << (JH_LUT_BITS - len);
-		const unsigned count = 1u << (JH_LUT_BITS - len);
-		for (unsigned i = 0; i < count && first + i < (1u << JH_LUT_BITS); ++i) {
-			if (lut->fast[first + i] == 0) {
-				lut->fast[first + i] = (uint16_t)((len << 8) | s->V[p]);
+		// longer code: second-level table of its JH_LUT_BITS-bit prefix, indexed by the next 6 bits
+		const unsigned prefix = ((unsigned)c.code[p] >> (len - JH_LUT_BITS)) & ((1u << JH_LUT_BITS) - 1u);
+		uint16_t &f = lut->fast[prefix];
+		if (f == 0) {
+			f = nsub < JH_SUB_TABLES ? (uint16_t)(0x8000u | (unsigned)nsub++) : (uint16_t)JH_LUT_SEARCH;
+		}
+		if (!(f & 0x8000u)) {
+			continue;                                          // prefix taken by a shorter code (malformed table)
+		}
+		if (f == JH_LUT_SEARCH) {
+			continue;
+		}
+		uint16_t *sub = lut->sub[f & 0x7fffu];
+		const unsigned first = ((unsigned)c.code[p] << (16 - len)) & 63u;
+		const unsigned count = 1u << (16 - len);
+		for (unsigned i = 0; i < count && first + i < 64u; ++i) {
+			if (sub[first + i] == 0) {
+				sub[first + i] = entry;
 			}
 		}
 	}

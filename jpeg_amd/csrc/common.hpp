@@ -23,11 +23,21 @@
 #define JH_CHAIN_MAX 16               // steps a speculative chain may walk before it is cut
 #define JH_SEQ_OWN (256 - JH_CHAIN_MAX)   // sub-sequences owned by one workgroup (the rest are ghosts)
 
-struct JhHuffLut {                    // one Huffman table, decoder view (Annex C / F.2.2.3)
-	uint16_t fast[1 << JH_LUT_BITS];  // (len << 8) | symbol for codes <= JH_LUT_BITS bits, else 0
+#define JH_SUB_TABLES 8               // second-level tables (64 entries) per Huffman table
+#define JH_LUT_SEARCH 0xffffu         // first-level entry: more long-code prefixes than second-level tables
+
+// One Huffman table, decoder view (Annex C / F.2.2.3).  Entry format of fast[] and sub[][]:
+//   bit 15 = 0: (total << 10) | (run << 4) | category, total = code length + category (<= 31),
+//               run = zero run, 63 for the EOB of an AC table; 0 = no code matches
+//   bit 15 = 1 (fast[] only): the code is longer than JH_LUT_BITS bits; the low bits name the
+//               second-level table indexed by the next 6 bits, JH_LUT_SEARCH = canonical search
+struct JhHuffLut {
+	uint16_t fast[1 << JH_LUT_BITS];
+	uint16_t sub[JH_SUB_TABLES][64];
 	uint32_t limit[17];               // limit[l] = (maxcode[l] + 1) << (16 - l), non-decreasing; l = 1..16
 	int32_t  offs[17];                // valptr[l] - mincode[l]
 	uint8_t  huffval[256];
+	uint8_t  pad[8];                  // sizeof is a multiple of 16 (table offsets are kept in units of 16)
 };
 
 struct JhHuffEnc {                    // one Huffman table, encoder view (EHUFCO/EHUFSI, huffman.c:118-148)

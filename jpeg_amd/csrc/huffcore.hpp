@@ -1,5 +1,13 @@
 // jpeg_amd/csrc/huffcore.hpp -- the per-thread Huffman decoding core shared by the synchronisation
-// kernels (huffsync.hip) and the scan / write kernels (huffdec.hip).  Device code only.
+// kernels (huffsync.hip) and the write kernel (huffdec.hip).  Device code only.
+//
+// One loop iteration = one Huffman symbol, DC and AC alike (read_dc / read_ac, coeffs.c:86-161):
+// the fast table yields (code length, zero run, category) with EOB pre-encoded as "run 63", so
+//     k = z + run;  coefficient k <- value;  z = k + 1;  z >= 64 ends the block
+// covers DC (z = 0, run = 0), (run, size) pairs, ZRL (run 15, category 0) and EOB without branches.
+// The bit stream is read through a small interface (LDS-staged window or global memory), the
+// 64-bit bit buffer is refilled one 32-bit word at a time and the next word is always in flight,
+// so the only load on the symbol-to-symbol critical path is the table look-up.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -7,8 +15,8 @@
 #include "kernels.hpp"
 
 struct DecTables {                    // workgroup-shared decode context (LDS)
-	uint8_t blk_dc[JH_MAX_MCU_BLOCKS], blk_ac[JH_MAX_MCU_BLOCKS], blk_comp[JH_MAX_MCU_BLOCKS];
-	uint8_t pad[2];
+	// per block of the MCU: (DC table offset / 16) | (AC table offset / 16) << 12 | component << 24
+	uint32_t info[JH_MAX_MCU_BLOCKS];
 };
 
 struct DecState {
@@ -26,79 +34,127 @@ __device__ __forceinline__ unsigned long long pack_state(const DecState &s)
 	       ((unsigned long long)(s.z & 0xff) << 40) | ((unsigned long long)(s.reset & 1) << 48);
 }
 
-__device__ __forceinline__ uint32_t load_be32(const uint8_t *cs, uint32_t word)
+// ---- bit-stream sources -------------------------------------------------------------------------
+
+// a window of the unstuffed stream staged in LDS as big-endian-corrected words; one padding word per
+// 32 (= one sub-sequence) so that lanes reading the same word of neighbouring sub-sequences hit
+// different banks
+struct LdsStream {
+	const uint32_t *sw;
+	uint32_t wbase;                   // stream word held by sw[0]
+	__device__ __forceinline__ uint32_t word(uint32_t w) const
+	{
+		const uint32_t x = w - wbase;
+		return sw[x + (x >> 5)];
+	}
+};
+
+struct GlobalStream {
+	const uint8_t *cs;
+	__device__ __forceinline__ uint32_t word(uint32_t w) const
+	{
+		return __builtin_bswap32(reinterpret_cast<const uint32_t *>(cs)[w]);
+	}
+};
+
+// cooperative fill of an LdsStream window: words [wbase, wbase + nwords) of cs (16-byte vector loads)
+__device__ __forceinline__ void stage_stream(uint32_t *sw, const uint8_t *cs, uint32_t wbase, uint32_t nwords)
 {
-	return __builtin_bswap32(reinterpret_cast<const uint32_t *>(cs)[word]);
+	const uint4 *src = reinterpret_cast<const uint4 *>(cs + (size_t)wbase * 4);   // wbase is a multiple of 32
+	for (uint32_t q = threadIdx.x; q * 4 < nwords; q += blockDim.x) {
+		const uint4 v = src[q];
+		const uint32_t x = q * 4;
+		uint32_t *d = sw + x + (x >> 5);          // the 4 words of a quad never straddle a padding slot
+		d[0] = __builtin_bswap32(v.x);
+		d[1] = __builtin_bswap32(v.y);
+		d[2] = __builtin_bswap32(v.z);
+		d[3] = __builtin_bswap32(v.w);
+	}
 }
 
-// F.12: extend the sign of a cat-bit magnitude field (coeffs.c:33-48)
-__device__ __forceinline__ int extend(unsigned extra, int cat)
-{
-	return cat == 0 ? 0 : ((extra >> (cat - 1)) ? (int)extra : (int)extra - (1 << cat) + 1);
-}
+#define JH_STREAM_LDS_WORDS(nsubseq) ((nsubseq) * 33 + 8)
+
+// per-thread DC accumulators live in LDS as [component][thread]: one ds_add per DC symbol instead
+// of a select chain over four registers
+#define DCS_AT(dcs, k, stride) ((dcs)[(k) * (stride)])
 
 // Decode every symbol that STARTS before bit `stop`, beginning at st.pos.  WRITE selects the final
 // pass (coefficients stored, st.dc = predictors, blk = index of the block in progress).
-template <bool WRITE>
-__device__ __forceinline__ void decode_span(DecState &st, const uint32_t stop, const uint8_t *cs,
+//
+// The hot loop is branch-free apart from three rarely taken exits (long code, end of a restart
+// segment, coefficient store): three stream words are kept in registers (w0:w1 hold the current
+// bit, w2 is the word after them, re-read every iteration so that it is there before a word
+// boundary is crossed), and the tables of the NEXT block of the MCU are fetched while the current
+// block is still being decoded.
+template <bool WRITE, class Stream>
+__device__ __forceinline__ void decode_span(DecState &st, const uint32_t stop, const Stream &S,
                                             const uint32_t total_bits, const uint32_t *seg_start,
-                                            const uint32_t nseg, const JhHuffLut *luts,
-                                            const DecTables &tb, const int B,
+                                            const uint32_t nseg, const unsigned char *luts,
+                                            const DecTables &tb, const int B, int *dcs, const int dcs_stride,
                                             int16_t *coefs, int blk, const int nblk)
 {
 	if (st.pos >= stop || st.pos >= total_bits) {
 		return;
 	}
+#pragma unroll
+	for (int k = 0; k < JH_MAX_COMP; ++k) {
+		DCS_AT(dcs, k, dcs_stride) = st.dc[k];
+	}
 	uint32_t seg_end = min(seg_start[st.seg + 1] * 8u, total_bits);
-	uint32_t wpos = st.pos >> 5;
-	unsigned long long buf = ((unsigned long long)load_be32(cs, wpos) << 32) | load_be32(cs, wpos + 1);
-	buf <<= (st.pos & 31u);
-	int avail = 64 - (int)(st.pos & 31u);
-	wpos += 2;
 	uint32_t pos = st.pos;
-	int c = st.c, z = st.z;
+	int c = st.c, z = st.z, nb = st.nb;
+	int cn = (c + 1 == B) ? 0 : c + 1;
+	uint32_t info = tb.info[c], info_n = tb.info[cn];
+	uint32_t wi = pos >> 5;
+	uint32_t w0 = S.word(wi), w1 = S.word(wi + 1), w2 = S.word(wi + 2);
 
 	while (pos < stop) {
-		if (avail < 32) {
-			buf |= (unsigned long long)load_be32(cs, wpos++) << (32 - avail);
-			avail += 32;
-		}
-		const JhHuffLut &lut = luts[z == 0 ? tb.blk_dc[c] : tb.blk_ac[c]];
-		unsigned e = lut.fast[(unsigned)(buf >> (64 - JH_LUT_BITS))];
-		int len = (int)(e >> 8);
-		unsigned sym = e & 0xffu;
-		bool invalid = false;
-		if (len == 0) {
-			// code longer than the fast table: canonical search on the left-aligned 16-bit window
-			const unsigned v = (unsigned)(buf >> 48);
-			len = JH_LUT_BITS + 1;
-#pragma unroll
-			for (int l = JH_LUT_BITS + 1; l < 16; ++l) {
-				len += v >= lut.limit[l] ? 1 : 0;
-			}
-			if (v >= lut.limit[16]) {
-				invalid = true;       // no code matches: the reference reads on to the end of the segment
-				sym = 0;
+		const uint32_t win = (uint32_t)((((unsigned long long)w0 << 32 | w1) << (pos & 31u)) >> 32);
+		const bool isdc = z == 0;
+		const unsigned char *lut = luts + (((info >> (isdc ? 0 : 12)) & 0xfffu) << 4);
+		unsigned e = reinterpret_cast<const uint16_t *>(lut)[win >> (32 - JH_LUT_BITS)];
+		if (e & 0x8000u) {
+			// code longer than the fast table
+			const JhHuffLut *L = reinterpret_cast<const JhHuffLut *>(lut);
+			if (e != JH_LUT_SEARCH) {
+				e = L->sub[e & 0x7fffu][(win >> (26 - JH_LUT_BITS)) & 63u];
 			} else {
-				sym = lut.huffval[(lut.offs[len] + (int)(v >> (16 - len))) & 0xff];
+				// canonical search on the left-aligned 16-bit window (more prefixes than second-level tables)
+				const unsigned v = win >> 16;
+				int len = JH_LUT_BITS + 1;
+#pragma unroll
+				for (int l = JH_LUT_BITS + 1; l < 16; ++l) {
+					len += v >= L->limit[l] ? 1 : 0;
+				}
+				e = 0;
+				if (v < L->limit[16]) {
+					const unsigned sym = L->huffval[(L->offs[len] + (int)(v >> (16 - len))) & 0xff];
+					const unsigned cat = sym & 15u;
+					const unsigned run = (!isdc && sym == 0) ? 63u : (sym >> 4);   // EOB (coeffs.c:241-243)
+					e = (((unsigned)len + cat) << 10) | (run << 4) | cat;
+				}
 			}
 		}
-		const int cat = (int)(sym & 15u);
-		const int total = len + cat;
-		if (invalid || pos + (uint32_t)total > seg_end) {
-			// end of this restart segment (padding bits, truncated data or garbage): decoder.c:376-381.
+		const int total = (int)(e >> 10), run = (int)((e >> 4) & 63u), cat = (int)(e & 15u);
+		const uint32_t npos = pos + (uint32_t)total;
+		if (e == 0 || npos > seg_end) {
+			// no code matches (the reference reads on to the end of the segment), or the data of this
+			// restart segment is used up (padding bits, truncated data): decoder.c:376-381.
 			// The MCU in progress is dropped (context->mblocks is not incremented), the next segment
 			// starts with block 0 / DC predictors 0 (decoder.c:369-373).
-			st.nb -= c;
+			nb -= c;
 			if (WRITE) {
 				blk -= c;
 			}
 			c = 0;
 			z = 0;
+			cn = B == 1 ? 0 : 1;
+			info = tb.info[0];
+			info_n = tb.info[cn];
 			st.reset = 1;
 #pragma unroll
 			for (int k = 0; k < JH_MAX_COMP; ++k) {
-				st.dc[k] = 0;
+				DCS_AT(dcs, k, dcs_stride) = 0;
 			}
 			st.seg++;
 			if (st.seg >= nseg) {
@@ -107,54 +163,57 @@ __device__ __forceinline__ void decode_span(DecState &st, const uint32_t stop, c
 			}
 			pos = seg_end;
 			seg_end = min(seg_start[st.seg + 1] * 8u, total_bits);
-			wpos = pos >> 5;
-			buf = ((unsigned long long)load_be32(cs, wpos) << 32) | load_be32(cs, wpos + 1);
-			buf <<= (pos & 31u);
-			avail = 64 - (int)(pos & 31u);
-			wpos += 2;
+			if (pos >= stop) {
+				break;
+			}
+			wi = pos >> 5;
+			w0 = S.word(wi);
+			w1 = S.word(wi + 1);
+			w2 = S.word(wi + 2);
 			continue;
 		}
-		const unsigned extra = cat ? (unsigned)((buf << len) >> (64 - cat)) : 0u;
-		buf <<= total;
-		avail -= total;
-		pos += (uint32_t)total;
-		if (z == 0) {
-			const int diff = extend(extra, cat);
-			const int comp = tb.blk_comp[c];
-			// dynamic index into a tiny array: keep it in registers with a select chain
-			int val = 0;
-#pragma unroll
-			for (int k = 0; k < JH_MAX_COMP; ++k) {
-				if (k == comp) {
-					st.dc[k] += diff;
-					val = st.dc[k];
-				}
-			}
-			if (WRITE && blk >= 0 && blk < nblk) {
-				coefs[(size_t)blk * 64] = (int16_t)val;      // DC un-prediction (decoder.c:351-355)
-			}
-			z = 1;
-		} else if (sym == 0) {
-			z = 64;                                            // EOB (coeffs.c:241-243)
+		// F.12: extend the sign of the cat-bit magnitude field that follows the code (coeffs.c:33-48)
+		const unsigned extra = __builtin_amdgcn_ubfe(win, 32u - (unsigned)total, (unsigned)cat);
+		int val = (int)extra - ((extra >> ((cat - 1) & 31)) ? 0 : (1 << cat) - 1);
+		int *dca = dcs + (info >> 24) * dcs_stride;
+		if (WRITE) {
+			const int old = atomicAdd(dca, isdc ? val : 0);     // DC un-prediction (decoder.c:351-355)
+			val += isdc ? old : 0;
 		} else {
-			z += (int)(sym >> 4);                              // zero run (coeffs.c:246)
-			if (WRITE && cat != 0 && z < 64 && blk >= 0 && blk < nblk) {
-				coefs[(size_t)blk * 64 + z] = (int16_t)extend(extra, cat);
-			}
-			z++;
+			atomicAdd(dca, isdc ? val : 0);
 		}
-		if (z >= 64) {
-			z = 0;
-			c = (c + 1 == B) ? 0 : c + 1;
-			st.nb++;
-			if (WRITE) {
-				blk++;
-			}
+		const int k = z + run;                                  // zero run (coeffs.c:246)
+		if (WRITE && (isdc || cat != 0) && k < 64 && blk >= 0 && blk < nblk) {
+			coefs[(size_t)blk * 64 + k] = (int16_t)val;
 		}
+		// advance the register window (a symbol is at most 31 bits: at most one word boundary)
+		const uint32_t nwi = npos >> 5;
+		const bool cross = nwi != wi;
+		w0 = cross ? w1 : w0;
+		w1 = cross ? w2 : w1;
+		wi = nwi;
+		pos = npos;
+		w2 = S.word(wi + 2);
+		// next zig-zag index / next block
+		const bool done = k >= 63;
+		z = done ? 0 : k + 1;
+		nb += done ? 1 : 0;
+		if (WRITE) {
+			blk += done ? 1 : 0;
+		}
+		c = done ? cn : c;
+		info = done ? info_n : info;
+		cn = (c + 1 == B) ? 0 : c + 1;
+		info_n = tb.info[cn];
 	}
 	st.pos = pos;
 	st.c = c;
 	st.z = z;
+	st.nb = nb;
+#pragma unroll
+	for (int k = 0; k < JH_MAX_COMP; ++k) {
+		st.dc[k] = DCS_AT(dcs, k, dcs_stride);
+	}
 }
 
 // segment that contains byte offset `byte` : largest k with seg_start[k] <= byte
@@ -172,7 +231,7 @@ __device__ __forceinline__ uint32_t find_segment(const uint32_t *seg_start, uint
 	return lo;
 }
 
-__device__ __forceinline__ void load_tables(const JhDecodeWork &w, const JhDecFrame &fr, JhHuffLut *luts, DecTables *tb,
+__device__ __forceinline__ void load_tables(const JhDecodeWork &w, const JhDecFrame &fr, unsigned char *luts, DecTables *tb,
                                             const JhGeom &g)
 {
 	const uint32_t *src = reinterpret_cast<const uint32_t *>(w.luts + fr.lut_off);
@@ -184,9 +243,9 @@ __device__ __forceinline__ void load_tables(const JhDecodeWork &w, const JhDecFr
 	if (threadIdx.x < JH_MAX_MCU_BLOCKS) {
 		// read through the global pointer: indexing the by-value copy would put it in scratch
 		const JhDecFrame *gf = w.frames + blockIdx.y;
-		tb->blk_dc[threadIdx.x] = gf->blk_dc[threadIdx.x];
-		tb->blk_ac[threadIdx.x] = gf->blk_ac[threadIdx.x];
-		tb->blk_comp[threadIdx.x] = (uint8_t)g.blk_comp[threadIdx.x];
+		const uint32_t unit = (uint32_t)(sizeof(JhHuffLut) / 16);
+		tb->info[threadIdx.x] = gf->blk_dc[threadIdx.x] * unit | (gf->blk_ac[threadIdx.x] * unit) << 12 |
+		                        (uint32_t)g.blk_comp[threadIdx.x] << 24;
 	}
 	__syncthreads();
 }
@@ -202,17 +261,6 @@ __device__ __forceinline__ void store_info(JhSubInfo *dst, const DecState &s)
 		r.dc[k] = s.dc[k];
 	}
 	*dst = r;
-}
-
-// chain state carried from one sub-sequence into the next: counters restart, position/phase stay
-__device__ __forceinline__ void next_subsequence(DecState &s)
-{
-	s.reset = 0;
-	s.nb = 0;
-#pragma unroll
-	for (int k = 0; k < JH_MAX_COMP; ++k) {
-		s.dc[k] = 0;
-	}
 }
 
 #define STATE_SYNC_MASK 0x0000ffffffffffffull      // pos, c, z (the reset flag is not part of the parse state)

@@ -404,8 +404,10 @@ __global__ __launch_bounds__(256) void k_huff_scan(const HuffArgs a)
 __global__ __launch_bounds__(256) void k_huff_write(const HuffArgs a)
 {
 	extern __shared__ __align__(16) unsigned char smem[];
-	JhHuffLut *luts = reinterpret_cast<JhHuffLut *>(smem);
+	unsigned char *luts = smem;
+	uint32_t *sw = reinterpret_cast<uint32_t *>(smem + sizeof(JhHuffLut) * a.w.max_luts);
 	__shared__ DecTables tb;
+	__shared__ int dcs[JH_MAX_COMP][256];
 
 	const JhDecodeWork &w = a.w;
 	const int f = blockIdx.y;
@@ -416,12 +418,16 @@ __global__ __launch_bounds__(256) void k_huff_write(const HuffArgs a)
 	if (blockIdx.x * 256u >= nsub) {
 		return;
 	}
+	const uint8_t *cs = w.cs + fr.cs_off;
+	LdsStream S;
+	S.sw = sw;
+	S.wbase = blockIdx.x * 256u * (JH_SUBSEQ_BITS / 32);
+	stage_stream(sw, cs, S.wbase, min(256u, nsub - blockIdx.x * 256u) * (JH_SUBSEQ_BITS / 32) + 4);
 	load_tables(w, fr, luts, &tb, a.g);
 	const uint32_t t = blockIdx.x * 256u + threadIdx.x;
 	if (t >= nsub) {
 		return;
 	}
-	const uint8_t *cs = w.cs + fr.cs_off;
 	const uint32_t *seg_start = w.seg_start + fr.seg_off;
 	const uint32_t nseg = min(fs.nseg, fr.seg_cap - 1);
 	const JhSubStart s0 = w.start[fr.sub_off + t];
@@ -440,7 +446,10 @@ __global__ __launch_bounds__(256) void k_huff_write(const HuffArgs a)
 	if (st.c >= a.g.B || st.z > 63 || st.seg >= nseg) {
 		return;                        // only reachable when the synchronisation did not converge
 	}
-	decode_span<true>(st, (t + 1) * JH_SUBSEQ_BITS, cs, total_bits, seg_start, nseg, luts, tb, a.g.B,
+	if (st.pos < t * JH_SUBSEQ_BITS) {
+		return;                        // entry before the staged window: only reachable when not converged
+	}
+	decode_span<true>(st, (t + 1) * JH_SUBSEQ_BITS, S, total_bits, seg_start, nseg, luts, tb, a.g.B, &dcs[0][threadIdx.x], 256,
 	                  w.coefs + (size_t)f * a.g.nblk * 64, s0.blk, a.g.nblk);
 }
 
@@ -451,7 +460,7 @@ int jh_launch_huff_decode(const JhDecodeWork &w, const JhGeom &g, hipStream_t s,
 	a.g = g;
 	a.round = 0;
 	// one launch configuration for the batch: LDS for the largest table set of any frame
-	size_t lds = sizeof(JhHuffLut) * (size_t)w.max_luts;
+	size_t lds = sizeof(JhHuffLut) * (size_t)w.max_luts + JH_STREAM_LDS_WORDS(256) * sizeof(uint32_t);
 	dim3 gsub((w.max_subs + 255) / 256, w.nframes);
 	if (jh_launch_huff_sync(w, g, s, extra_sync_rounds != 0, th)) {
 		return -1;

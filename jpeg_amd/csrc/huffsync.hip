@@ -35,7 +35,7 @@
 
 #define KMAX JH_CHAIN_MAX
 #define OWN JH_SEQ_OWN
-#define DIRN 6                          // distinct exit states remembered per sub-sequence
+#define DIRN 4                          // distinct exit states remembered per sub-sequence
 #define NONE16 0xffffu
 #define NONE32 0xffffffffu
 
@@ -78,8 +78,10 @@ __device__ __forceinline__ void compact_append(bool keep, uint16_t value, uint16
 __global__ __launch_bounds__(256) void k_huff_chains(const HuffArgs a)
 {
 	extern __shared__ __align__(16) unsigned char smem[];
-	JhHuffLut *luts = reinterpret_cast<JhHuffLut *>(smem);
+	unsigned char *luts = smem;
+	uint32_t *sw = reinterpret_cast<uint32_t *>(smem + sizeof(JhHuffLut) * a.w.max_luts);
 	__shared__ DecTables tb;
+	__shared__ int dcs[JH_MAX_COMP][256];
 	__shared__ unsigned long long dkey[256][DIRN];
 	__shared__ uint16_t downer[256][DIRN];
 	__shared__ uint8_t dcnt[256];
@@ -113,6 +115,11 @@ __global__ __launch_bounds__(256) void k_huff_chains(const HuffArgs a)
 	const int tid = threadIdx.x;
 	const int range_len = (int)min(256u, nsub - j0);      // own + ghost sub-sequences of this workgroup
 	JhSubInfo *rec = w.rec + (size_t)(fr.sub_off + j0) * (KMAX + 1);
+	LdsStream S;
+	S.sw = sw;
+	S.wbase = j0 * (JH_SUBSEQ_BITS / 32);
+	stage_stream(sw, cs, S.wbase, (uint32_t)range_len * (JH_SUBSEQ_BITS / 32) + 4);
+	int *mydcs = &dcs[0][tid];
 
 	// ---- step 0: every chain decodes its own sub-sequence -------------------------------------
 	if (tid < 2) {
@@ -129,7 +136,7 @@ __global__ __launch_bounds__(256) void k_huff_chains(const HuffArgs a)
 			const uint32_t t = j0 + tid;
 			state_from(st, (unsigned long long)t * JH_SUBSEQ_BITS, 0);
 			st.seg = nseg > 1 ? find_segment(seg_start, nseg, st.pos >> 3) : 0u;
-			decode_span<false>(st, (t + 1) * JH_SUBSEQ_BITS, cs, total_bits, seg_start, nseg, luts, tb, a.g.B, nullptr, 0, 0);
+			decode_span<false>(st, (t + 1) * JH_SUBSEQ_BITS, S, total_bits, seg_start, nseg, luts, tb, a.g.B, mydcs, 256, nullptr, 0, 0);
 			if (tid < OWN) {
 				store_info(&rec[(size_t)tid * (KMAX + 1)], st);
 			}
@@ -164,7 +171,7 @@ __global__ __launch_bounds__(256) void k_huff_chains(const HuffArgs a)
 			const int jl = i + d;
 			DecState st;
 			state_from(st, cstate[i], cseg[i]);
-			decode_span<false>(st, (j0 + jl + 1) * JH_SUBSEQ_BITS, cs, total_bits, seg_start, nseg, luts, tb, a.g.B, nullptr, 0, 0);
+			decode_span<false>(st, (j0 + jl + 1) * JH_SUBSEQ_BITS, S, total_bits, seg_start, nseg, luts, tb, a.g.B, mydcs, 256, nullptr, 0, 0);
 			if (i < OWN) {
 				store_info(&rec[(size_t)i * (KMAX + 1) + d], st);
 			}
@@ -262,8 +269,9 @@ __global__ __launch_bounds__(256) void k_huff_chains(const HuffArgs a)
 __global__ __launch_bounds__(64) void k_huff_fix(const HuffArgs a)
 {
 	extern __shared__ __align__(16) unsigned char smem[];
-	JhHuffLut *luts = reinterpret_cast<JhHuffLut *>(smem);
+	unsigned char *luts = smem;
 	__shared__ DecTables tb;
+	__shared__ int dcs[JH_MAX_COMP][64];
 
 	const JhDecodeWork &w = a.w;
 	const int f = blockIdx.y;
@@ -327,7 +335,7 @@ __global__ __launch_bounds__(64) void k_huff_fix(const HuffArgs a)
 			atomicAdd(&fs.changed[a.round], 1u);   // raced with a neighbour's rewrite: redo next round
 			return;
 		}
-		decode_span<false>(st, (jn + 1) * JH_SUBSEQ_BITS, cs, total_bits, seg_start, nseg, luts, tb, a.g.B, nullptr, 0, 0);
+		decode_span<false>(st, (jn + 1) * JH_SUBSEQ_BITS, GlobalStream{cs}, total_bits, seg_start, nseg, luts, tb, a.g.B, &dcs[0][threadIdx.x], 64, nullptr, 0, 0);
 		store_info(&truth[jn], st);
 		const unsigned long long key = chain_key(pack_state(st), st.seg);
 		const uint32_t lo = jn > (uint32_t)KMAX ? jn - KMAX : 0u;
@@ -356,10 +364,16 @@ int jh_launch_huff_sync(const JhDecodeWork &w, const JhGeom &g, hipStream_t s, b
 	a.g = g;
 	a.round = 0;
 	const size_t lds = sizeof(JhHuffLut) * (size_t)w.max_luts;
+	const size_t lds_chains = lds + JH_STREAM_LDS_WORDS(256) * sizeof(uint32_t);
 	const unsigned nwg = (w.max_subs + OWN - 1) / OWN;
 	if (!resync_only) {
+		// static + dynamic LDS of this kernel exceeds the 64 KB default limit
+		if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_huff_chains), hipFuncAttributeMaxDynamicSharedMemorySize,
+		                        (int)lds_chains) != hipSuccess) {
+			return -1;
+		}
 		JH_T_BEGIN(th, "k_huff_chains", s);
-		hipLaunchKernelGGL(k_huff_chains, dim3(nwg, w.nframes), dim3(256), lds, s, a);
+		hipLaunchKernelGGL(k_huff_chains, dim3(nwg, w.nframes), dim3(256), lds_chains, s, a);
 		JH_T_END(th, s);
 	}
 	JH_T_BEGIN(th, "k_huff_fix", s);
