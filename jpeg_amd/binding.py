@@ -29,7 +29,8 @@ EXPORTS = [
     "jpeg_hip_decoder_create", "jpeg_hip_decoder_destroy", "jpeg_hip_decoder_prepare",
     "jpeg_hip_decoder_info", "jpeg_hip_decoder_frame_bytes", "jpeg_hip_decoder_run",
     "jpeg_hip_decoder_sync", "jpeg_hip_decoder_get_coefficients", "jpeg_hip_decoder_set_timing",
-    "jpeg_hip_decoder_get_timing", "jpeg_hip_decoder_ecs_bytes",
+    "jpeg_hip_decoder_get_timing", "jpeg_hip_decoder_ecs_bytes", "jpeg_hip_decoder_get_stats",
+    "jpeg_hip_decoder_set_debug",
     "jpeg_hip_encoder_create", "jpeg_hip_encoder_destroy", "jpeg_hip_encoder_configure",
     "jpeg_hip_encoder_info", "jpeg_hip_encoder_run", "jpeg_hip_encoder_sync",
     "jpeg_hip_encoder_get_jpeg", "jpeg_hip_encoder_device_jpeg", "jpeg_hip_encoder_get_coefficients",
@@ -95,6 +96,9 @@ def lib():
         L.jpeg_hip_decoder_set_timing.restype = None
         L.jpeg_hip_decoder_get_timing.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int]
         L.jpeg_hip_decoder_ecs_bytes.argtypes = [vp, C.POINTER(sz)]
+        L.jpeg_hip_decoder_get_stats.argtypes = [vp, C.c_int, C.POINTER(C.c_uint32)]
+        L.jpeg_hip_decoder_set_debug.argtypes = [vp, C.c_int]
+        L.jpeg_hip_decoder_set_debug.restype = None
         L.jpeg_hip_encoder_create.argtypes = [C.POINTER(vp), C.c_int]
         L.jpeg_hip_encoder_destroy.argtypes = [vp]
         L.jpeg_hip_encoder_destroy.restype = None
@@ -197,6 +201,17 @@ class Decoder:
         st = (C.c_int * self.n)()
         self.L.jpeg_hip_decoder_sync(self.h, st)
         return list(st)
+
+    def stats(self, frame=0):
+        """(serial fallback used, workgroups repaired, blocks decoded, restart segments) of one frame"""
+        out = (C.c_uint32 * 4)()
+        err = self.L.jpeg_hip_decoder_get_stats(self.h, frame, out)
+        if err:
+            raise JpegError(err, "jpeg_hip_decoder_get_stats")
+        return tuple(int(v) for v in out)
+
+    def set_debug(self, flags):
+        self.L.jpeg_hip_decoder_set_debug(self.h, int(flags))
 
     def ecs_bytes(self):
         v = (C.c_size_t * self.n)()

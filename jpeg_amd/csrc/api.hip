@@ -147,9 +147,9 @@ struct jpeg_hip_decoder {
 	// device
 	uint8_t *d_raw = nullptr, *d_cs = nullptr;
 	uint32_t *d_seg = nullptr, *d_chunk_kept = nullptr, *d_chunk_rst = nullptr;
-	JhSubInfo *d_sub = nullptr, *d_rec = nullptr;
-	uint32_t *d_meta = nullptr, *d_wg_exit = nullptr;
-	int *d_onfrom = nullptr;
+	JhSubInfo *d_rec = nullptr;
+	uint32_t *d_meta = nullptr;
+	JhWgAgg *d_wg_agg = nullptr, *d_wg_base = nullptr;
 	JhSubStart *d_start = nullptr;
 	JhDecFrame *d_frames = nullptr;
 	JhDecState *d_state = nullptr;
@@ -162,16 +162,17 @@ struct jpeg_hip_decoder {
 	size_t last_stride = 0;
 	hipStream_t last_stream = nullptr;
 	bool ran = false;
+	int debug = 0;
 	StageTimer timer;
 
 	void release()
 	{
 		hipFree(d_raw); hipFree(d_cs); hipFree(d_seg); hipFree(d_chunk_kept); hipFree(d_chunk_rst);
-		hipFree(d_sub); hipFree(d_start); hipFree(d_frames); hipFree(d_state); hipFree(d_luts);
-		hipFree(d_quant); hipFree(d_coefs); hipFree(d_rec); hipFree(d_meta); hipFree(d_wg_exit); hipFree(d_onfrom);
-		d_rec = nullptr; d_meta = d_wg_exit = nullptr; d_onfrom = nullptr;
+		hipFree(d_start); hipFree(d_frames); hipFree(d_state); hipFree(d_luts);
+		hipFree(d_quant); hipFree(d_coefs); hipFree(d_rec); hipFree(d_meta); hipFree(d_wg_agg); hipFree(d_wg_base);
+		d_rec = nullptr; d_meta = nullptr; d_wg_agg = d_wg_base = nullptr;
 		d_raw = d_cs = nullptr; d_seg = d_chunk_kept = d_chunk_rst = nullptr;
-		d_sub = nullptr; d_start = nullptr; d_frames = nullptr; d_state = nullptr; d_luts = nullptr;
+		d_start = nullptr; d_frames = nullptr; d_state = nullptr; d_luts = nullptr;
 		d_quant = nullptr; d_coefs = nullptr;
 	}
 };
@@ -360,15 +361,14 @@ extern "C" int jpeg_hip_decoder_prepare(jpeg_hip_decoder *dec, int nframes,
 	HIPCHK(hipMalloc((void **)&dec->d_seg, dec->seg_entries * 4));
 	HIPCHK(hipMalloc((void **)&dec->d_chunk_kept, dec->chunk_entries * 4));
 	HIPCHK(hipMalloc((void **)&dec->d_chunk_rst, dec->chunk_entries * 4));
-	HIPCHK(hipMalloc((void **)&dec->d_sub, dec->sub_entries * sizeof(JhSubInfo)));
 	HIPCHK(hipMalloc((void **)&dec->d_start, dec->sub_entries * sizeof(JhSubStart)));
 	HIPCHK(hipMalloc((void **)&dec->d_rec, dec->sub_entries * (JH_CHAIN_MAX + 1) * sizeof(JhSubInfo)));
 	HIPCHK(hipMalloc((void **)&dec->d_meta, dec->sub_entries * sizeof(uint32_t)));
-	HIPCHK(hipMalloc((void **)&dec->d_onfrom, dec->sub_entries * sizeof(int)));
-	HIPCHK(hipMalloc((void **)&dec->d_wg_exit, (wg_off + 4) * sizeof(uint32_t)));
+	HIPCHK(hipMalloc((void **)&dec->d_wg_agg, (wg_off + 4) * sizeof(JhWgAgg)));
+	HIPCHK(hipMalloc((void **)&dec->d_wg_base, (wg_off + 4) * sizeof(JhWgAgg)));
 	HIPCHK(hipMemset(dec->d_meta, 0, dec->sub_entries * sizeof(uint32_t)));
-	HIPCHK(hipMemset(dec->d_onfrom, 0xff, dec->sub_entries * sizeof(int)));
-	HIPCHK(hipMemset(dec->d_wg_exit, 0xff, (wg_off + 4) * sizeof(uint32_t)));
+	HIPCHK(hipMemset(dec->d_wg_agg, 0, (wg_off + 4) * sizeof(JhWgAgg)));
+	HIPCHK(hipMemset(dec->d_wg_base, 0, (wg_off + 4) * sizeof(JhWgAgg)));
 	HIPCHK(hipMalloc((void **)&dec->d_frames, nframes * sizeof(JhDecFrame)));
 	HIPCHK(hipMalloc((void **)&dec->d_state, nframes * sizeof(JhDecState)));
 	HIPCHK(hipMalloc((void **)&dec->d_luts, luts.size() * sizeof(JhHuffLut)));
@@ -392,11 +392,10 @@ extern "C" int jpeg_hip_decoder_prepare(jpeg_hip_decoder *dec, int nframes,
 	w.seg_start = dec->d_seg;
 	w.chunk_kept = dec->d_chunk_kept;
 	w.chunk_rst = dec->d_chunk_rst;
-	w.sub = dec->d_sub;
 	w.rec = dec->d_rec;
 	w.meta = dec->d_meta;
-	w.onfrom = dec->d_onfrom;
-	w.wg_exit = dec->d_wg_exit;
+	w.wg_agg = dec->d_wg_agg;
+	w.wg_base = dec->d_wg_base;
 	w.start = dec->d_start;
 	w.frames = dec->d_frames;
 	w.state = dec->d_state;
@@ -406,6 +405,7 @@ extern "C" int jpeg_hip_decoder_prepare(jpeg_hip_decoder *dec, int nframes,
 	w.max_chunks = max_chunks;
 	w.max_subs = max_subs;
 	w.max_luts = max_luts;
+	w.debug = dec->debug;
 	return RET_SUCCESS;
 }
 
@@ -435,36 +435,20 @@ __global__ void k_dec_init(JhDecState *st, int n)
 	}
 }
 
-__global__ void k_dec_reset_rounds(JhDecState *st, int n)
-{
-	const int i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i < n) {
-		// a resync continues with full walks in rounds 1..JH_SYNC_ITERS: round 0 counts as "changed"
-		st[i].changed[0] = 1;
-		for (int r = 1; r <= JH_SYNC_ITERS; ++r) {
-			st[i].changed[r] = 0;
-		}
-	}
-}
-
-static int decoder_launch(jpeg_hip_decoder *dec, hipStream_t s, bool resync_only)
+static int decoder_launch(jpeg_hip_decoder *dec, hipStream_t s)
 {
 	const JhDecodeWork &w = dec->work;
 	const JhTimerHook th = dec->timer.hook();
 	const size_t coef_bytes = (size_t)dec->nframes * dec->g.nblk * 64 * sizeof(int16_t);
-	if (!resync_only) {
-		hipLaunchKernelGGL(k_dec_init, dim3((dec->nframes + 63) / 64), dim3(64), 0, s, dec->d_state, dec->nframes);
-		if (jh_launch_ecs_unstuff(w, s, &th)) {
-			return RET_FAILURE_LOGIC_ERROR;
-		}
-	} else {
-		hipLaunchKernelGGL(k_dec_reset_rounds, dim3((dec->nframes + 63) / 64), dim3(64), 0, s, dec->d_state, dec->nframes);
+	hipLaunchKernelGGL(k_dec_init, dim3((dec->nframes + 63) / 64), dim3(64), 0, s, dec->d_state, dec->nframes);
+	if (jh_launch_ecs_unstuff(w, s, &th)) {
+		return RET_FAILURE_LOGIC_ERROR;
 	}
 	dec->timer.begin("coef_clear", s);
 	// alloc_buffers() zero-fills int_buffer (common.c:129): blocks the stream never reaches stay 0
 	HIPCHK(hipMemsetAsync(dec->d_coefs, 0, coef_bytes, s));
 	dec->timer.end(s);
-	if (jh_launch_huff_decode(w, dec->g, s, resync_only ? 1 : 0, &th)) {
+	if (jh_launch_huff_decode(w, dec->g, s, &th)) {
 		return RET_FAILURE_LOGIC_ERROR;
 	}
 	dec->timer.begin("k_decode_pixels", s);
@@ -488,7 +472,7 @@ extern "C" int jpeg_hip_decoder_run(jpeg_hip_decoder *dec, void *d_samples, size
 	dec->last_stride = frame_stride;
 	dec->last_stream = (hipStream_t)stream;
 	dec->timer.reset();
-	int err = decoder_launch(dec, dec->last_stream, false);
+	int err = decoder_launch(dec, dec->last_stream);
 	dec->ran = err == RET_SUCCESS;
 	return err;
 }
@@ -499,27 +483,8 @@ extern "C" int jpeg_hip_decoder_sync(jpeg_hip_decoder *dec, int *frame_status)
 		return RET_FAILURE_LOGIC_ERROR;
 	}
 	HIPCHK(hipSetDevice(dec->device));
-	for (int attempt = 0;; ++attempt) {
-		HIPCHK(hipStreamSynchronize(dec->last_stream));
-		HIPCHK(hipMemcpy(dec->state.data(), dec->d_state, dec->nframes * sizeof(JhDecState), hipMemcpyDeviceToHost));
-		bool pending = false;
-		for (int f = 0; f < dec->nframes; ++f) {
-			if (dec->parse_err[f] == 0 && (dec->state[f].status & JH_ST_NOT_CONVERGED)) {
-				pending = true;
-			}
-		}
-		if (!pending) {
-			break;
-		}
-		if (attempt >= 4096) {
-			return RET_FAILURE_LOGIC_ERROR;
-		}
-		// rare: a chain needed more than JH_SYNC_ITERS rounds to fall into step; run more rounds
-		int err = decoder_launch(dec, dec->last_stream, true);
-		if (err) {
-			return err;
-		}
-	}
+	HIPCHK(hipStreamSynchronize(dec->last_stream));
+	HIPCHK(hipMemcpy(dec->state.data(), dec->d_state, dec->nframes * sizeof(JhDecState), hipMemcpyDeviceToHost));
 	int worst = RET_SUCCESS;
 	for (int f = 0; f < dec->nframes; ++f) {
 		int st = dec->parse_err[f];
@@ -564,6 +529,25 @@ extern "C" int jpeg_hip_decoder_get_timing(jpeg_hip_decoder *dec, const char **n
 {
 	hipSetDevice(dec->device);
 	return dec->timer.collect(names, ms, cap);
+}
+
+extern "C" int jpeg_hip_decoder_get_stats(const jpeg_hip_decoder *dec, int frame, uint32_t stats[4])
+{
+	if (!dec || !dec->ran || frame < 0 || frame >= dec->nframes) {
+		return RET_FAILURE_LOGIC_ERROR;
+	}
+	const JhDecState &s = dec->state[frame];
+	stats[0] = (s.status & JH_ST_SERIAL) ? 1u : 0u;
+	stats[1] = s.nrepaired;
+	stats[2] = s.nblocks;
+	stats[3] = s.nseg;
+	return RET_SUCCESS;
+}
+
+extern "C" void jpeg_hip_decoder_set_debug(jpeg_hip_decoder *dec, int flags)
+{
+	dec->debug = flags;
+	dec->work.debug = flags;
 }
 
 extern "C" int jpeg_hip_decoder_ecs_bytes(const jpeg_hip_decoder *dec, size_t *ecs_len)

@@ -19,9 +19,10 @@
 #define JH_LUT_BITS 10                // fast table index width
 #define JH_SUBSEQ_BITS 1024           // bits per speculative sub-sequence (one thread each)
 #define JH_SUBSEQ_BYTES (JH_SUBSEQ_BITS / 8)
-#define JH_SYNC_ITERS 3               // fix-up rounds launched per run (more only if the device asks)
 #define JH_CHAIN_MAX 16               // steps a speculative chain may walk before it is cut
 #define JH_SEQ_OWN (256 - JH_CHAIN_MAX)   // sub-sequences owned by one workgroup (the rest are ghosts)
+// chains workgroup b covers sub-sequences [b * OWN, b * OWN + 256) and EMITS the entry records of
+// [b * OWN + (b ? JH_CHAIN_MAX : 0), b * OWN + 256): the first JH_CHAIN_MAX belong to its predecessor
 
 #define JH_SUB_TABLES 8               // second-level tables (64 entries) per Huffman table
 #define JH_LUT_SEARCH 0xffffu         // first-level entry: more long-code prefixes than second-level tables
@@ -86,11 +87,27 @@ struct JhSubInfo {
 	int32_t  dc[JH_MAX_COMP];         // sum of DC differences per component since the last reset
 };
 
-struct JhSubStart {                   // entry of a sub-sequence for the write pass (after the scan)
-	unsigned long long state;
+struct JhSubStart {                   // entry of a sub-sequence for the write pass, RELATIVE to its chains workgroup
+	unsigned long long state;         // parse state at entry; bit 48: a restart boundary lies between the
+	                                  // workgroup's first emitted sub-sequence and this one
 	uint32_t seg;
-	int32_t  blk;                     // index of the block in progress
-	int32_t  pred[JH_MAX_COMP];       // DC predictors
+	int32_t  blk;                     // blocks completed before, inside the workgroup's emitted range
+	int32_t  pred[JH_MAX_COMP];       // DC sums since the range start / the last restart boundary
+};
+
+enum {                                // JhWgAgg.flags
+	JH_AGG_RESET = 1,                 // a restart boundary lies inside the emitted range
+	JH_AGG_BAD_NEXT = 2,              // the NEXT workgroup's default seed does not join the true parse in time
+};
+#define JH_SEED_NONE 0xffffffffu
+
+struct JhWgAgg {                      // one chains workgroup: totals of its emitted range (or exclusive prefix)
+	int32_t  nb;
+	uint32_t flags;
+	int32_t  dc[JH_MAX_COMP];
+	uint32_t next_seed;               // chain (local index in the NEXT workgroup) | first sub-sequence << 8 that
+	                                  // carries the true parse there, JH_SEED_NONE if unknown
+	uint32_t pad;
 };
 
 #ifdef __HIPCC__
@@ -98,6 +115,12 @@ struct JhSubStart {                   // entry of a sub-sequence for the write p
 #else
 #define JH_HD
 #endif
+
+// number of chains workgroups that emit something for a stream of nsub sub-sequences
+JH_HD static inline uint32_t jh_num_chain_wgs(uint32_t nsub)
+{
+	return nsub <= 256u ? 1u : 1u + (nsub - 256u + JH_SEQ_OWN - 1u) / JH_SEQ_OWN;
+}
 
 // zig-zag position -> raster index (common.h:34-43)
 static const uint8_t jh_zigzag[64] = {

@@ -273,132 +273,6 @@ int jh_launch_ecs_unstuff(const JhDecodeWork &w, hipStream_t s, const JhTimerHoo
 	return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-// ===================================================================================== 4. scan
-
-// One workgroup per frame: exclusive prefix over the sub-sequence records.
-//   blocks : plain sum (the reference's mblocks counter runs across restart markers, decoder.c:381)
-//   DC     : restart-segmented sum (predictors return to 0 at every boundary, decoder.c:371-373)
-__global__ __launch_bounds__(256) void k_huff_scan(const HuffArgs a)
-{
-	__shared__ int s_nb[256];
-	__shared__ int s_dc[JH_MAX_COMP][256];
-	__shared__ int s_rs[256];
-
-	const JhDecodeWork &w = a.w;
-	const int f = blockIdx.x;
-	const JhDecFrame fr = w.frames[f];
-	JhDecState &fs = w.state[f];
-	const uint32_t total_bits = fs.cs_len * 8u;
-	const uint32_t nsub = (total_bits + JH_SUBSEQ_BITS - 1) / JH_SUBSEQ_BITS;
-	const JhSubInfo *sub = w.sub + fr.sub_off;
-	JhSubStart *start = w.start + fr.sub_off;
-	const int tid = threadIdx.x;
-
-	int carry_nb = 0, carry_dc[JH_MAX_COMP] = {0, 0, 0, 0};
-	for (uint32_t t0 = 0; t0 < nsub; t0 += 256) {
-		const uint32_t t = t0 + tid;
-		JhSubInfo me;
-		me.state = 0;
-		me.seg = 0;
-		me.nb = 0;
-#pragma unroll
-		for (int k = 0; k < JH_MAX_COMP; ++k) {
-			me.dc[k] = 0;
-		}
-		if (t < nsub) {
-			me = sub[t];
-		}
-		int nb = me.nb, rs = (int)((me.state >> 48) & 1);
-		int dc[JH_MAX_COMP];
-#pragma unroll
-		for (int k = 0; k < JH_MAX_COMP; ++k) {
-			dc[k] = me.dc[k];
-		}
-		// inclusive Hillis-Steele scan with the segmented operator
-		for (int o = 1; o < 256; o <<= 1) {
-			s_nb[tid] = nb;
-			s_rs[tid] = rs;
-#pragma unroll
-			for (int k = 0; k < JH_MAX_COMP; ++k) {
-				s_dc[k][tid] = dc[k];
-			}
-			__syncthreads();
-			if (tid >= o) {
-				nb += s_nb[tid - o];
-				if (!rs) {
-#pragma unroll
-					for (int k = 0; k < JH_MAX_COMP; ++k) {
-						dc[k] += s_dc[k][tid - o];
-					}
-				}
-				rs |= s_rs[tid - o];
-			}
-			__syncthreads();
-		}
-		// fold in the carry of the previous tiles
-		const int inc_nb = carry_nb + nb;
-		int inc_dc[JH_MAX_COMP];
-#pragma unroll
-		for (int k = 0; k < JH_MAX_COMP; ++k) {
-			inc_dc[k] = rs ? dc[k] : carry_dc[k] + dc[k];
-		}
-		// publish inclusive values so that the neighbour can read its exclusive prefix
-		s_nb[tid] = inc_nb;
-#pragma unroll
-		for (int k = 0; k < JH_MAX_COMP; ++k) {
-			s_dc[k][tid] = inc_dc[k];
-		}
-		__syncthreads();
-		if (t < nsub) {
-			JhSubStart o;
-			if (tid == 0) {
-				o.blk = carry_nb;
-#pragma unroll
-				for (int k = 0; k < JH_MAX_COMP; ++k) {
-					o.pred[k] = carry_dc[k];
-				}
-			} else {
-				o.blk = s_nb[tid - 1];
-#pragma unroll
-				for (int k = 0; k < JH_MAX_COMP; ++k) {
-					o.pred[k] = s_dc[k][tid - 1];
-				}
-			}
-			if (t == 0) {
-				o.state = 0;           // a DC code of block 0 starts at bit 0
-				o.seg = 0;
-			} else {
-				const JhSubInfo p = sub[t - 1];
-				o.state = p.state & STATE_SYNC_MASK;
-				o.seg = p.seg;
-			}
-			start[t] = o;
-		}
-		const int last_nb = s_nb[255];
-		int last_dc[JH_MAX_COMP];
-#pragma unroll
-		for (int k = 0; k < JH_MAX_COMP; ++k) {
-			last_dc[k] = s_dc[k][255];
-		}
-		__syncthreads();
-		carry_nb = last_nb;
-#pragma unroll
-		for (int k = 0; k < JH_MAX_COMP; ++k) {
-			carry_dc[k] = last_dc[k];
-		}
-	}
-	if (tid == 0) {
-		fs.nblocks = (uint32_t)carry_nb;
-		// did the synchronisation reach its fixed point?
-		const bool conv = fs.changed[a.round] == 0;
-		if (!conv) {
-			fs.status |= JH_ST_NOT_CONVERGED;
-		} else {
-			fs.status &= ~(uint32_t)JH_ST_NOT_CONVERGED;
-		}
-	}
-}
-
 // ===================================================================================== 5. write pass
 
 __global__ __launch_bounds__(256) void k_huff_write(const HuffArgs a)
@@ -430,7 +304,13 @@ __global__ __launch_bounds__(256) void k_huff_write(const HuffArgs a)
 	}
 	const uint32_t *seg_start = w.seg_start + fr.seg_off;
 	const uint32_t nseg = min(fs.nseg, fr.seg_cap - 1);
+	// entry record: relative to the chains workgroup that emitted it (huffsync.hip), plus that
+	// workgroup's base.  blocks: plain sum (the reference's mblocks counter runs across restart markers,
+	// decoder.c:381); DC predictors: back to 0 at every restart boundary (decoder.c:371-373)
 	const JhSubStart s0 = w.start[fr.sub_off + t];
+	const uint32_t cb = t < 256u ? 0u : (t - JH_CHAIN_MAX) / JH_SEQ_OWN;
+	const JhWgAgg base = w.wg_base[fr.wg_off + cb];
+	const bool cut = (s0.state >> 48) & 1;
 
 	DecState st;
 	st.pos = (uint32_t)(s0.state & 0xffffffffu);
@@ -441,19 +321,17 @@ __global__ __launch_bounds__(256) void k_huff_write(const HuffArgs a)
 	st.nb = 0;
 #pragma unroll
 	for (int k = 0; k < JH_MAX_COMP; ++k) {
-		st.dc[k] = s0.pred[k];
+		st.dc[k] = cut ? s0.pred[k] : base.dc[k] + s0.pred[k];
 	}
-	if (st.c >= a.g.B || st.z > 63 || st.seg >= nseg) {
-		return;                        // only reachable when the synchronisation did not converge
-	}
-	if (st.pos < t * JH_SUBSEQ_BITS) {
-		return;                        // entry before the staged window: only reachable when not converged
+	const int blk0 = base.nb + s0.blk;
+	if (st.c >= a.g.B || st.z > 63 || st.seg >= nseg || st.pos < t * JH_SUBSEQ_BITS) {
+		return;                        // cannot happen for records produced by decode_span
 	}
 	decode_span<true>(st, (t + 1) * JH_SUBSEQ_BITS, S, total_bits, seg_start, nseg, luts, tb, a.g.B, &dcs[0][threadIdx.x], 256,
-	                  w.coefs + (size_t)f * a.g.nblk * 64, s0.blk, a.g.nblk);
+	                  w.coefs + (size_t)f * a.g.nblk * 64, blk0, a.g.nblk);
 }
 
-int jh_launch_huff_decode(const JhDecodeWork &w, const JhGeom &g, hipStream_t s, int extra_sync_rounds, const JhTimerHook *th)
+int jh_launch_huff_decode(const JhDecodeWork &w, const JhGeom &g, hipStream_t s, const JhTimerHook *th)
 {
 	HuffArgs a;
 	a.w = w;
@@ -462,14 +340,9 @@ int jh_launch_huff_decode(const JhDecodeWork &w, const JhGeom &g, hipStream_t s,
 	// one launch configuration for the batch: LDS for the largest table set of any frame
 	size_t lds = sizeof(JhHuffLut) * (size_t)w.max_luts + JH_STREAM_LDS_WORDS(256) * sizeof(uint32_t);
 	dim3 gsub((w.max_subs + 255) / 256, w.nframes);
-	if (jh_launch_huff_sync(w, g, s, extra_sync_rounds != 0, th)) {
+	if (jh_launch_huff_sync(w, g, s, th)) {
 		return -1;
 	}
-	// the scan checks the LAST fix-up round that ran: no exit changed there = fixed point
-	a.round = extra_sync_rounds != 0 ? JH_SYNC_ITERS : JH_SYNC_ITERS - 1;
-	JH_T_BEGIN(th, "k_huff_scan", s);
-	hipLaunchKernelGGL(k_huff_scan, dim3(w.nframes), dim3(256), 0, s, a);
-	JH_T_END(th, s);
 	JH_T_BEGIN(th, "k_huff_write", s);
 	hipLaunchKernelGGL(k_huff_write, gsub, dim3(256), lds, s, a);
 	JH_T_END(th, s);

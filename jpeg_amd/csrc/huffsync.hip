@@ -4,27 +4,31 @@
 // the decoder started at the first bit of sub-sequence t with the guess (DC code of block 0 next).
 // Chain 0 is the true parse.  Huffman streams self-synchronise, so chain t soon coincides with the
 // true parse -- but a JPEG decoder's state is (bit position, block-in-MCU, zig-zag index) and the
-// block phase only locks by chance, so a few chains stay wrong for a long time.  Waiting for EVERY
-// chain (the obvious protocol, profiles/r01_a) costs ~255 sparse steps per workgroup.  Instead:
+// block phase only locks by chance, so a few chains stay wrong for a long time.  Therefore:
 //
-//   k_huff_chains   (one workgroup = JH_SEQ_OWN own + JH_CHAIN_MAX ghost sub-sequences)
+//   k_huff_chains   (one workgroup = JH_SEQ_OWN own + JH_CHAIN_MAX ghost sub-sequences, stream in LDS)
 //     step 0   every chain decodes its own sub-sequence;
 //     step d   every chain still alive decodes sub-sequence t + d and looks its exit state up in a
 //              small per-sub-sequence directory (LDS) of the exit states YOUNGER chains had there.
 //              Equal state = identical future: the chain records a link to the younger chain and
-//              stops.  Chains are compacted every step, so sparse steps cost few wave-instructions;
-//              after JH_CHAIN_MAX steps the survivors (wrong, irrelevant parses) are cut.
-//     The links form a forest.  The true parse is a PATH in it: on chain r until r merges, then on
-//     the chain r merged into, ...  The path from the workgroup's first chain (the "canonical"
-//     path) is marked by pointer doubling (8 rounds) and every sub-sequence j gets the record of the
-//     path chain that covers it: its exit state, blocks completed and DC sums, decoded from the
-//     TRUE entry state.  For the first workgroup of a frame the canonical path is the true parse.
-//   k_huff_fix      (one thread per workgroup boundary)
-//     walks the true path from the previous workgroup's exit chain until it joins this workgroup's
-//     canonical path (a few hops), rewriting the records of those first sub-sequences.  If the true
-//     path reaches a cut chain it decodes on by itself until it meets a stored chain again, which
-//     guarantees progress for ANY stream.  A walk that does not join changes that workgroup's exit;
-//     rounds repeat (full walks) until nothing changes -- in practice the first round is final.
+//              stops.  A chain that runs into garbage (no code matches, no restart segment left) is
+//              linked to the chain that starts at the next sub-sequence ("restart link"): fine for a
+//              guess, flagged so that it is never trusted on the true parse.  Alive chains are
+//              compacted every step; after JH_CHAIN_MAX steps the survivors are cut.
+//     The links form a forest; the true parse is a PATH in it.  The workgroup marks the path from
+//     its first chain (pointer doubling) and emits, for every sub-sequence on it from the
+//     JH_CHAIN_MAX-th on, the record decoded from the path's state, the exclusive prefix of blocks /
+//     DC sums inside the workgroup and the workgroup's totals.  The first JH_CHAIN_MAX sub-sequences
+//     are emitted by the PREVIOUS workgroup, whose path has long joined the true parse there; it also
+//     follows the next workgroup's first chain through its ghost zone and checks that both paths
+//     leave the zone in the same state -- which proves, workgroup by workgroup from the frame's first
+//     one (whose first chain IS the true parse), that every emitted record is on the true parse.
+//   k_huff_repair   a workgroup whose first chain did not join in time (a few in a thousand) re-emits from
+//     the chain its predecessor names as the carrier of the true parse.
+//   k_huff_finish   exclusive scan of the workgroup totals (one wave per frame).  Frames where the
+//     checks above failed twice in a row, or whose true parse contains garbage (corrupt streams: the
+//     reference skips to the end of the segment, decoder.c:376-381), are walked serially instead:
+//     slow, but right for ANY stream.
 //
 // Restart markers need nothing extra: crossing a restart boundary puts every chain into the same
 // state, so all chains merge there at the latest.
@@ -37,7 +41,7 @@
 #define OWN JH_SEQ_OWN
 #define DIRN 4                          // distinct exit states remembered per sub-sequence
 #define NONE16 0xffffu
-#define NONE32 0xffffffffu
+#define META_RESTART 0x80000000u
 
 // parse state + restart segment as one comparable word (segment modulo 2^16: two chains at the same
 // bit position can only differ by the boundaries processed AT that position)
@@ -75,6 +79,246 @@ __device__ __forceinline__ void compact_append(bool keep, uint16_t value, uint16
 	}
 }
 
+// ---- the segmented sum of (blocks, DC sums): a restart boundary cuts the DC sums -----------------------
+
+struct Agg {
+	int nb, rs;
+	int dc[JH_MAX_COMP];
+};
+
+__device__ __forceinline__ Agg agg_identity()
+{
+	Agg a;
+	a.nb = 0;
+	a.rs = 0;
+#pragma unroll
+	for (int k = 0; k < JH_MAX_COMP; ++k) {
+		a.dc[k] = 0;
+	}
+	return a;
+}
+
+__device__ __forceinline__ Agg agg_combine(const Agg &a, const Agg &b)      // a comes first
+{
+	Agg r;
+	r.nb = a.nb + b.nb;
+	r.rs = a.rs | b.rs;
+#pragma unroll
+	for (int k = 0; k < JH_MAX_COMP; ++k) {
+		r.dc[k] = b.rs ? b.dc[k] : a.dc[k] + b.dc[k];
+	}
+	return r;
+}
+
+__device__ __forceinline__ Agg agg_shfl_up(const Agg &a, int o)
+{
+	Agg r;
+	r.nb = __shfl_up(a.nb, o, 64);
+	r.rs = __shfl_up(a.rs, o, 64);
+#pragma unroll
+	for (int k = 0; k < JH_MAX_COMP; ++k) {
+		r.dc[k] = __shfl_up(a.dc[k], o, 64);
+	}
+	return r;
+}
+
+// inclusive / exclusive scan over the lanes of a wave, lane order
+__device__ __forceinline__ void wave_seg_scan(const Agg &v, Agg &incl, Agg &excl)
+{
+	const int lane = threadIdx.x & 63;
+	Agg x = v;
+#pragma unroll
+	for (int o = 1; o < 64; o <<= 1) {
+		const Agg y = agg_shfl_up(x, o);
+		if (lane >= o) {
+			x = agg_combine(y, x);
+		}
+	}
+	incl = x;
+	const Agg e = agg_shfl_up(x, 1);
+	excl = lane == 0 ? agg_identity() : e;
+}
+
+// over the threads of a 256-thread workgroup, thread order; scratch = 4 entries of LDS
+__device__ __forceinline__ void block_seg_scan(const Agg &v, Agg *scratch, Agg &incl, Agg &excl)
+{
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	Agg wi, we;
+	wave_seg_scan(v, wi, we);
+	if (lane == 63) {
+		scratch[wv] = wi;
+	}
+	__syncthreads();
+	Agg pre = agg_identity();
+	for (int i = 0; i < wv; ++i) {
+		pre = agg_combine(pre, scratch[i]);
+	}
+	incl = agg_combine(pre, wi);
+	excl = agg_combine(pre, we);
+	__syncthreads();
+}
+
+__device__ __forceinline__ Agg agg_of(const JhSubInfo &r)
+{
+	Agg a;
+	a.nb = r.nb;
+	a.rs = (int)((r.state >> 48) & 1);
+#pragma unroll
+	for (int k = 0; k < JH_MAX_COMP; ++k) {
+		a.dc[k] = r.dc[k];
+	}
+	return a;
+}
+
+// ---- path selection and emission (shared by k_huff_chains and k_huff_repair) ---------------------------
+
+struct PathLds {
+	uint16_t succ[256];               // chain this chain merged into (local index), NONE16 = none
+	uint8_t nst[256];                 // steps walked: the chain covers local sub-sequences [i, i + nst]
+	uint8_t dflag[256];               // its link is a restart link (garbage before it)
+	uint16_t reach[2][256];
+	uint8_t mark[256];
+	uint16_t pred[256];
+	uint8_t cov[256];
+	JhSubInfo trec[256];              // records of the marked path, by local sub-sequence
+	Agg scratch[4];
+	int s_last, from_last;            // path chain that covers the last sub-sequence of the range, and since where
+	int broken;
+	int have2;
+	unsigned long long key2;
+};
+
+// marks the chains on the path that starts with chain `seed`; pred[] = predecessor on the path
+__device__ __forceinline__ void mark_path(PathLds &L, int seed)
+{
+	const int tid = threadIdx.x;
+	L.reach[0][tid] = L.succ[tid];
+	L.mark[tid] = tid == seed ? 1 : 0;
+	L.pred[tid] = NONE16;
+	__syncthreads();
+	int rb = 0;
+	for (int k = 0; k < 8; ++k) {
+		const unsigned r = L.reach[rb][tid];
+		if (L.mark[tid] && r != NONE16) {
+			L.mark[r] = 1;
+		}
+		L.reach[rb ^ 1][tid] = r != NONE16 ? L.reach[rb][r] : (uint16_t)NONE16;
+		__syncthreads();
+		rb ^= 1;
+	}
+	if (L.mark[tid] && L.succ[tid] != NONE16) {
+		L.pred[L.succ[tid]] = (uint16_t)tid;
+	}
+	__syncthreads();
+}
+
+struct EmitResult {
+	uint32_t flags_next;              // JH_AGG_BAD_NEXT or 0
+	uint32_t next_seed;
+	bool broken;
+};
+
+// Emits start[] for the local sub-sequences [lo, range_len) from the path that starts with chain
+// `seed` (trusted from local sub-sequence seed_from on), returns the totals through *total and what
+// the next workgroup needs to know.  rec = records of local chain 0; first = first workgroup of the frame.
+__device__ __forceinline__ EmitResult emit_path(PathLds &L, const JhSubInfo *rec, JhSubStart *start, int seed, int seed_from,
+                                                int lo, int range_len, bool first, bool need_next, Agg *total)
+{
+	const int tid = threadIdx.x;
+	const int hi = range_len - 1;
+	if (tid == 0) {
+		L.s_last = -1;
+		L.from_last = 0;
+		L.broken = 0;
+		L.have2 = 0;
+	}
+	L.cov[tid] = 0;
+	mark_path(L, seed);
+	{
+		const bool onp = L.mark[tid] && tid < range_len;
+		if (onp) {
+			const int from = tid == seed ? seed_from : (int)L.pred[tid] + (int)L.nst[L.pred[tid]] + 1;
+			const int to = tid + (int)L.nst[tid];
+			for (int jl = max(from, 0); jl <= min(to, hi); ++jl) {
+				L.trec[jl] = rec[(size_t)tid * (KMAX + 1) + (jl - tid)];
+				L.cov[jl] = 1;
+			}
+			if (L.dflag[tid] && to >= lo - 1 && to < hi) {
+				L.broken = 1;              // the true parse itself ran into garbage: not for this scheme
+			}
+			if (from <= hi && hi <= to) {
+				L.s_last = tid;
+				L.from_last = from;
+			}
+		}
+	}
+	__syncthreads();
+	if (tid >= max(lo - 1, 0) && tid <= hi && !L.cov[tid]) {
+		L.broken = 1;                      // a chain on the path was cut before it merged
+	}
+	__syncthreads();
+	const bool broken = L.broken != 0;
+	const int s1 = L.s_last, from1 = L.from_last;
+
+	// prefix of blocks and DC sums over the emitted range, entry records
+	Agg v = agg_identity();
+	if (!broken && tid >= lo && tid <= hi) {
+		v = agg_of(L.trec[tid]);
+	}
+	Agg incl, excl;
+	block_seg_scan(v, L.scratch, incl, excl);
+	if (!broken && tid >= lo && tid <= hi) {
+		JhSubStart o;
+		if (tid == 0 && first) {
+			o.state = 0;                   // a DC code of block 0 starts at bit 0
+			o.seg = 0;
+		} else {
+			o.state = L.trec[tid - 1].state & STATE_SYNC_MASK;
+			o.seg = L.trec[tid - 1].seg;
+		}
+		o.state |= (unsigned long long)(excl.rs & 1) << 48;
+		o.blk = excl.nb;
+#pragma unroll
+		for (int k = 0; k < JH_MAX_COMP; ++k) {
+			o.pred[k] = excl.dc[k];
+		}
+		start[tid] = o;
+	}
+	if (tid == 255) {
+		*total = incl;
+	}
+
+	// what the next workgroup needs: does its first chain leave our ghost zone in the true state?
+	EmitResult res;
+	res.broken = broken;
+	res.flags_next = 0;
+	res.next_seed = JH_SEED_NONE;
+	if (need_next && !broken) {
+		const unsigned long long key1 = chain_key(L.trec[hi].state, L.trec[hi].seg);
+		__syncthreads();
+		mark_path(L, OWN);
+		if (L.mark[tid] && tid >= OWN && tid < range_len) {
+			const int from = tid == OWN ? OWN : (int)L.pred[tid] + (int)L.nst[L.pred[tid]] + 1;
+			const int to = tid + (int)L.nst[tid];
+			if (from <= hi && hi <= to) {
+				const JhSubInfo r = rec[(size_t)tid * (KMAX + 1) + (hi - tid)];
+				L.key2 = chain_key(r.state, r.seg);
+				L.have2 = 1;
+			}
+		}
+		__syncthreads();
+		const bool ok = L.have2 && L.key2 == key1;
+		res.flags_next = ok ? 0u : (uint32_t)JH_AGG_BAD_NEXT;
+		if (s1 >= OWN) {
+			res.next_seed = (uint32_t)(s1 - OWN) | ((uint32_t)(from1 - OWN) << 8);
+		}
+	}
+	__syncthreads();
+	return res;
+}
+
+// =================================================================================== chains
+
 __global__ __launch_bounds__(256) void k_huff_chains(const HuffArgs a)
 {
 	extern __shared__ __align__(16) unsigned char smem[];
@@ -89,13 +333,8 @@ __global__ __launch_bounds__(256) void k_huff_chains(const HuffArgs a)
 	__shared__ uint32_t cseg[256];
 	__shared__ uint16_t alive[2][256];
 	__shared__ int nalive[2];
-	__shared__ uint16_t succ[256];
-	__shared__ uint8_t nst[256];
-	__shared__ uint16_t reach[2][256];
-	__shared__ uint8_t mark[256];
-	__shared__ uint16_t pred[256];
-	__shared__ int path_last_cov;
-	__shared__ unsigned exit_chain;
+	__shared__ PathLds P;
+	__shared__ Agg total;
 
 	const JhDecodeWork &w = a.w;
 	const int f = blockIdx.y;
@@ -103,10 +342,11 @@ __global__ __launch_bounds__(256) void k_huff_chains(const HuffArgs a)
 	const JhDecState fs = w.state[f];
 	const uint32_t total_bits = fs.cs_len * 8u;
 	const uint32_t nsub = (total_bits + JH_SUBSEQ_BITS - 1) / JH_SUBSEQ_BITS;
-	const uint32_t j0 = blockIdx.x * (uint32_t)OWN;
-	if (j0 >= nsub) {
+	const uint32_t b = blockIdx.x;
+	if (nsub == 0 || b >= jh_num_chain_wgs(nsub)) {
 		return;
 	}
+	const uint32_t j0 = b * (uint32_t)OWN;
 	load_tables(w, fr, luts, &tb, a.g);
 
 	const uint8_t *cs = w.cs + fr.cs_off;
@@ -126,8 +366,9 @@ __global__ __launch_bounds__(256) void k_huff_chains(const HuffArgs a)
 		nalive[tid] = 0;
 	}
 	dcnt[tid] = 0;
-	nst[tid] = 0;
-	succ[tid] = NONE16;
+	P.nst[tid] = 0;
+	P.dflag[tid] = 0;
+	P.succ[tid] = NONE16;
 	__syncthreads();
 	{
 		bool keep = false;
@@ -137,16 +378,24 @@ __global__ __launch_bounds__(256) void k_huff_chains(const HuffArgs a)
 			state_from(st, (unsigned long long)t * JH_SUBSEQ_BITS, 0);
 			st.seg = nseg > 1 ? find_segment(seg_start, nseg, st.pos >> 3) : 0u;
 			decode_span<false>(st, (t + 1) * JH_SUBSEQ_BITS, S, total_bits, seg_start, nseg, luts, tb, a.g.B, mydcs, 256, nullptr, 0, 0);
-			if (tid < OWN) {
-				store_info(&rec[(size_t)tid * (KMAX + 1)], st);
+			// identical bytes are written by the neighbour workgroup for the chains both of them walk
+			store_info(&rec[(size_t)tid * (KMAX + 1)], st);
+			const bool more = tid + 1 < range_len;
+			if (st.pos >= total_bits && t + 1 < nsub) {
+				// garbage: restart with the next chain's guess
+				if (more) {
+					P.succ[tid] = (uint16_t)(tid + 1);
+					P.dflag[tid] = 1;
+				}
+			} else {
+				const unsigned long long ps = pack_state(st);
+				dkey[tid][0] = chain_key(ps, st.seg);
+				downer[tid][0] = (uint16_t)tid;
+				dcnt[tid] = 1;
+				cstate[tid] = ps;
+				cseg[tid] = st.seg;
+				keep = more;
 			}
-			const unsigned long long ps = pack_state(st);
-			dkey[tid][0] = chain_key(ps, st.seg);
-			downer[tid][0] = (uint16_t)tid;
-			dcnt[tid] = 1;
-			cstate[tid] = ps;
-			cseg[tid] = st.seg;
-			keep = tid + 1 < range_len;
 		}
 		compact_append(keep, (uint16_t)tid, alive[0], &nalive[0]);
 	}
@@ -172,33 +421,37 @@ __global__ __launch_bounds__(256) void k_huff_chains(const HuffArgs a)
 			DecState st;
 			state_from(st, cstate[i], cseg[i]);
 			decode_span<false>(st, (j0 + jl + 1) * JH_SUBSEQ_BITS, S, total_bits, seg_start, nseg, luts, tb, a.g.B, mydcs, 256, nullptr, 0, 0);
-			if (i < OWN) {
-				store_info(&rec[(size_t)i * (KMAX + 1) + d], st);
-			}
-			const unsigned long long ps = pack_state(st);
-			const unsigned long long key = chain_key(ps, st.seg);
-			const int cnt = dcnt[jl];
-			int hit = -1;
-			for (int e = 0; e < cnt; ++e) {
-				if (dkey[jl][e] == key) {
-					hit = downer[jl][e];
+			store_info(&rec[(size_t)i * (KMAX + 1) + d], st);
+			P.nst[i] = (uint8_t)d;
+			const bool more = jl + 1 < range_len;
+			if (st.pos >= total_bits && j0 + jl + 1 < nsub) {
+				if (more) {
+					P.succ[i] = (uint16_t)(jl + 1);
+					P.dflag[i] = 1;
 				}
-			}
-			if (hit >= 0) {
-				succ[i] = (uint16_t)hit;           // same state as a younger chain: identical from here on
-				nst[i] = (uint8_t)d;
 			} else {
-				if (cnt < DIRN) {
-					dkey[jl][cnt] = key;
-					downer[jl][cnt] = (uint16_t)i;
-					dcnt[jl] = (uint8_t)(cnt + 1);
+				const unsigned long long ps = pack_state(st);
+				const unsigned long long key = chain_key(ps, st.seg);
+				const int cnt = dcnt[jl];
+				int hit = -1;
+				for (int e = 0; e < cnt; ++e) {
+					if (dkey[jl][e] == key) {
+						hit = downer[jl][e];
+					}
 				}
-				if (d == KMAX || jl + 1 >= range_len) {
-					nst[i] = (uint8_t)d;           // cut: still an unmerged parse at the horizon
+				if (hit >= 0) {
+					P.succ[i] = (uint16_t)hit;       // same state as a younger chain: identical from here on
 				} else {
-					keep = true;
-					cstate[i] = ps;
-					cseg[i] = st.seg;
+					if (cnt < DIRN) {
+						dkey[jl][cnt] = key;
+						downer[jl][cnt] = (uint16_t)i;
+						dcnt[jl] = (uint8_t)(cnt + 1);
+					}
+					if (d < KMAX && more) {
+						keep = true;
+						cstate[i] = ps;
+						cseg[i] = st.seg;
+					}
 				}
 			}
 		}
@@ -207,66 +460,218 @@ __global__ __launch_bounds__(256) void k_huff_chains(const HuffArgs a)
 	}
 	__syncthreads();
 
-	// ---- canonical path: chains reachable from this workgroup's first chain (pointer doubling) ----
-	reach[0][tid] = succ[tid];
-	mark[tid] = tid == 0 ? 1 : 0;
-	pred[tid] = NONE16;
+	// ---- links of the own chains (for the repair kernel and the serial walk) ---------------------
+	const bool need_next = b + 1 < jh_num_chain_wgs(nsub);
+	if ((tid < OWN || !need_next) && tid < range_len) {
+		const uint32_t link = P.succ[tid] != NONE16 ? (uint32_t)(P.succ[tid] - tid) : 0u;
+		w.meta[fr.sub_off + j0 + tid] = (uint32_t)P.nst[tid] | (link << 8) | (P.dflag[tid] ? META_RESTART : 0u);
+	}
+
+	// ---- emit from the path of the first chain ---------------------------------------------------
+	const EmitResult er = emit_path(P, rec, w.start + fr.sub_off + j0, 0, 0, b == 0 ? 0 : KMAX, range_len, b == 0, need_next, &total);
 	if (tid == 0) {
-		path_last_cov = -1;
-		exit_chain = NONE32;
-	}
-	__syncthreads();
-	int rb = 0;
-	for (int k = 0; k < 8; ++k) {
-		const unsigned r = reach[rb][tid];
-		if (mark[tid] && r != NONE16) {
-			mark[r] = 1;
+		JhWgAgg o;
+		o.nb = total.nb;
+		o.flags = (total.rs ? (uint32_t)JH_AGG_RESET : 0u) | er.flags_next;
+		if ((w.debug & 1) && need_next && (b & 1) == 0) {
+			o.flags |= (uint32_t)JH_AGG_BAD_NEXT;  // test hook: make the successor take the repair path
 		}
-		reach[rb ^ 1][tid] = r != NONE16 ? reach[rb][r] : (uint16_t)NONE16;
-		__syncthreads();
-		rb ^= 1;
-	}
-	if (mark[tid] && succ[tid] != NONE16) {
-		pred[succ[tid]] = (uint16_t)tid;
-	}
-	__syncthreads();
-	// chain s covers local sub-sequences [from, to]: from the step after its predecessor merged into it
-	const bool onp = mark[tid] && tid < range_len;
-	int from = 0, to = -1;
-	if (onp) {
-		from = tid == 0 ? 0 : (int)pred[tid] + (int)nst[pred[tid]] + 1;
-		to = tid + (int)nst[tid];
-		if (succ[tid] == NONE16) {
-			path_last_cov = to;
+#pragma unroll
+		for (int k = 0; k < JH_MAX_COMP; ++k) {
+			o.dc[k] = total.dc[k];
 		}
-	}
-	__syncthreads();
-	const int need = min(range_len, OWN + 1);               // own sub-sequences + the hand-over one
-	const bool broken = path_last_cov < need - 1;
-	JhSubInfo *truth = w.sub + fr.sub_off + j0;
-	if (onp && !broken) {
-		const int hi = min(min(to, OWN - 1), range_len - 1);
-		for (int jl = from; jl <= hi; ++jl) {
-			truth[jl] = rec[(size_t)tid * (KMAX + 1) + (jl - tid)];
+		o.next_seed = er.next_seed;
+		o.pad = 0;
+		w.wg_agg[fr.wg_off + b] = o;
+		if (er.broken || (w.debug & 2)) {
+			atomicOr(&w.state[f].status, (uint32_t)JH_ST_SERIAL);
 		}
-		if (from <= OWN && OWN <= to) {
-			exit_chain = j0 + (uint32_t)tid;               // carries the true parse into the next workgroup
-		}
-	}
-	__syncthreads();
-	if (tid < OWN && tid < range_len) {
-		const uint32_t link = succ[tid] != NONE16 ? (uint32_t)(succ[tid] - tid) : 0u;
-		w.meta[fr.sub_off + j0 + tid] = (uint32_t)nst[tid] | (link << 8);
-		w.onfrom[fr.sub_off + j0 + tid] = (onp && !broken) ? (int)(j0 + (uint32_t)from) : -1;
-	}
-	if (tid == 0) {
-		w.wg_exit[fr.wg_off + blockIdx.x] = broken ? NONE32 : exit_chain;
 	}
 }
 
-// ===================================================================================== fix-up walk
+// =================================================================================== repair
 
-__global__ __launch_bounds__(64) void k_huff_fix(const HuffArgs a)
+__global__ __launch_bounds__(256) void k_huff_repair(const HuffArgs a)
+{
+	__shared__ PathLds P;
+	__shared__ Agg total;
+
+	const JhDecodeWork &w = a.w;
+	const int f = blockIdx.y;
+	const uint32_t b = blockIdx.x + 1;
+	const JhDecFrame fr = w.frames[f];
+	const JhDecState fs = w.state[f];
+	const uint32_t total_bits = fs.cs_len * 8u;
+	const uint32_t nsub = (total_bits + JH_SUBSEQ_BITS - 1) / JH_SUBSEQ_BITS;
+	if (nsub == 0 || b >= jh_num_chain_wgs(nsub) || (fs.status & JH_ST_SERIAL)) {
+		return;
+	}
+	const JhWgAgg prev = w.wg_agg[fr.wg_off + b - 1];
+	if (!(prev.flags & JH_AGG_BAD_NEXT)) {
+		return;                            // the common case: the first chain joined the true parse in time
+	}
+	const int tid = threadIdx.x;
+	// the predecessor's own path must be beyond doubt, and it must know the carrier
+	const bool prev_bad = b >= 2 && (w.wg_agg[fr.wg_off + b - 2].flags & JH_AGG_BAD_NEXT);
+	if (prev_bad || prev.next_seed == JH_SEED_NONE) {
+		if (tid == 0) {
+			atomicOr(&w.state[f].status, (uint32_t)JH_ST_SERIAL);
+		}
+		return;
+	}
+	const uint32_t j0 = b * (uint32_t)OWN;
+	const int range_len = (int)min(256u, nsub - j0);
+	const uint32_t *meta = w.meta + fr.sub_off + j0;
+	JhSubInfo *rec = w.rec + (size_t)(fr.sub_off + j0) * (KMAX + 1);
+	{
+		uint16_t su = NONE16;
+		uint8_t ns = 0, df = 0;
+		if (tid < range_len) {
+			const uint32_t m = meta[tid];
+			int steps = (int)(m & 0xffu);
+			const int link = (int)((m >> 8) & 0xffu);
+			if (tid + steps > range_len - 1 || (link != 0 && tid + link > range_len - 1)) {
+				steps = min(steps, range_len - 1 - tid);   // the range ends before the chain does
+			} else if (link != 0) {
+				su = (uint16_t)(tid + link);
+				df = (m & META_RESTART) ? 1 : 0;
+			}
+			ns = (uint8_t)steps;
+		}
+		P.succ[tid] = su;
+		P.nst[tid] = ns;
+		P.dflag[tid] = df;
+	}
+	__syncthreads();
+	const int seed = (int)(prev.next_seed & 0xffu), seed_from = (int)(prev.next_seed >> 8);
+	const bool need_next = b + 1 < jh_num_chain_wgs(nsub);
+	const EmitResult er = emit_path(P, rec, w.start + fr.sub_off + j0, seed, seed_from, KMAX, range_len, false, need_next, &total);
+	if (tid == 0) {
+		JhWgAgg *o = &w.wg_agg[fr.wg_off + b];
+		// BAD_NEXT / next_seed stay as they are (the successor may be reading them right now); if the
+		// repaired path disagrees with them the frame is walked serially
+		const bool differs = need_next && ((o->flags & JH_AGG_BAD_NEXT) != er.flags_next || o->next_seed != er.next_seed);
+		if (er.broken || differs) {
+			atomicOr(&w.state[f].status, (uint32_t)JH_ST_SERIAL);
+		} else {
+			atomicAdd(&w.state[f].nrepaired, 1u);
+			o->nb = total.nb;
+#pragma unroll
+			for (int k = 0; k < JH_MAX_COMP; ++k) {
+				o->dc[k] = total.dc[k];
+			}
+			o->flags = (o->flags & (uint32_t)JH_AGG_BAD_NEXT) | (total.rs ? (uint32_t)JH_AGG_RESET : 0u);
+		}
+	}
+}
+
+// =================================================================================== finish
+
+// serial walk of one frame by one thread: every sub-sequence gets its entry record in ABSOLUTE form
+// (the workgroup bases are set to the identity).  Follows stored chains where they carry the true
+// parse, decodes by itself where none does.
+__device__ void serial_walk(const HuffArgs &a, const JhDecFrame &fr, JhDecState &fs, uint32_t nsub, uint32_t nwg,
+                            const unsigned char *luts, const DecTables &tb, int *dcs)
+{
+	const JhDecodeWork &w = a.w;
+	const uint32_t total_bits = fs.cs_len * 8u;
+	const uint8_t *cs = w.cs + fr.cs_off;
+	const uint32_t *seg_start = w.seg_start + fr.seg_off;
+	const uint32_t nseg = min(fs.nseg, fr.seg_cap - 1);
+	const JhSubInfo *rec = w.rec + (size_t)fr.sub_off * (KMAX + 1);
+	const uint32_t *meta = w.meta + fr.sub_off;
+	JhSubStart *start = w.start + fr.sub_off;
+
+	Agg acc = agg_identity();
+	unsigned long long T = 0;              // true entry state of sub-sequence jn
+	uint32_t Tseg = 0;
+	uint32_t r = 0xffffffffu;              // stored chain known to carry the true parse INTO sub-sequence jn
+	for (uint32_t jn = 0; jn < nsub; ++jn) {
+		JhSubStart o;
+		o.state = T & STATE_SYNC_MASK;
+		o.seg = Tseg;
+		o.blk = acc.nb;
+#pragma unroll
+		for (int k = 0; k < JH_MAX_COMP; ++k) {
+			o.pred[k] = acc.dc[k];
+		}
+		start[jn] = o;
+
+		JhSubInfo R;
+		const unsigned long long keyT = chain_key(T, Tseg);
+		if ((uint32_t)(T & 0xffffffffu) >= total_bits) {
+			// the parse has ended (end of data, or garbage with no restart segment left)
+			R.state = T & STATE_SYNC_MASK;
+			R.seg = Tseg;
+			R.nb = 0;
+#pragma unroll
+			for (int k = 0; k < JH_MAX_COMP; ++k) {
+				R.dc[k] = 0;
+			}
+			r = 0xffffffffu;
+		} else {
+			if (r == 0xffffffffu) {
+				// a stored chain that ENTERS jn in the true state?  chain jn itself, or an older one
+				const uint32_t lo = jn > (uint32_t)KMAX ? jn - KMAX : 0u;
+				for (uint32_t c = jn + 1; c-- > lo && r == 0xffffffffu;) {
+					const uint32_t mc = meta[c];
+					const uint32_t steps = mc & 0xffu;
+					if (jn - c > steps) {
+						continue;
+					}
+					if (c == jn) {
+						const uint32_t p0 = jn * JH_SUBSEQ_BITS;
+						const uint32_t s0 = nseg > 1 ? find_segment(seg_start, nseg, p0 >> 3) : 0u;
+						if (chain_key((unsigned long long)p0, s0) == keyT) {
+							r = c;
+						}
+					} else {
+						const JhSubInfo x = rec[(size_t)c * (KMAX + 1) + (jn - 1 - c)];
+						if (chain_key(x.state, x.seg) == keyT) {
+							r = c;
+						}
+					}
+				}
+			}
+			if (r != 0xffffffffu) {
+				const uint32_t m = meta[r];
+				const uint32_t steps = m & 0xffu, link = (m >> 8) & 0xffu, d = jn - r;
+				R = rec[(size_t)r * (KMAX + 1) + d];
+				if (d == steps) {
+					// the chain ends here: follow a true merge, never a restart link
+					r = (link != 0 && !(m & META_RESTART)) ? r + link : 0xffffffffu;
+				}
+			} else {
+				DecState st;
+				state_from(st, T, Tseg);
+				if (st.c >= a.g.B || st.z > 63 || st.seg >= nseg) {
+					st.pos = total_bits;       // cannot happen for states produced by decode_span
+				}
+				decode_span<false>(st, (jn + 1) * JH_SUBSEQ_BITS, GlobalStream{cs}, total_bits, seg_start, nseg, luts, tb, a.g.B, dcs, 64, nullptr, 0, 0);
+				store_info(&R, st);
+			}
+		}
+		acc = agg_combine(acc, agg_of(R));
+		T = R.state;
+		Tseg = R.seg;
+	}
+	fs.nblocks = (uint32_t)acc.nb;
+	for (uint32_t b = 0; b < nwg; ++b) {
+		JhWgAgg z;
+		z.nb = 0;
+		z.flags = 0;
+#pragma unroll
+		for (int k = 0; k < JH_MAX_COMP; ++k) {
+			z.dc[k] = 0;
+		}
+		z.next_seed = JH_SEED_NONE;
+		z.pad = 0;
+		w.wg_base[fr.wg_off + b] = z;
+	}
+}
+
+// one wave per frame: exclusive scan of the workgroup totals, or the serial walk
+__global__ __launch_bounds__(64) void k_huff_finish(const HuffArgs a)
 {
 	extern __shared__ __align__(16) unsigned char smem[];
 	unsigned char *luts = smem;
@@ -277,87 +682,62 @@ __global__ __launch_bounds__(64) void k_huff_fix(const HuffArgs a)
 	const int f = blockIdx.y;
 	const JhDecFrame fr = w.frames[f];
 	JhDecState &fs = w.state[f];
-	if (a.round > 0 && fs.changed[a.round - 1] == 0) {
-		return;                            // fixed point reached in an earlier round (changed[] stays 0)
-	}
 	const uint32_t total_bits = fs.cs_len * 8u;
 	const uint32_t nsub = (total_bits + JH_SUBSEQ_BITS - 1) / JH_SUBSEQ_BITS;
-	const uint32_t nwg = (nsub + OWN - 1) / OWN;
-	if (blockIdx.x * 64u >= nwg) {
+	if (nsub == 0) {
 		return;
 	}
-	load_tables(w, fr, luts, &tb, a.g);
-	const uint32_t b = blockIdx.x * 64u + threadIdx.x;
-	if (b >= nwg) {
+	const uint32_t nwg = jh_num_chain_wgs(nsub);
+	if (fs.status & JH_ST_SERIAL) {
+		load_tables(w, fr, luts, &tb, a.g);
+		if (threadIdx.x == 0) {
+			serial_walk(a, fr, fs, nsub, nwg, luts, tb, &dcs[0][0]);
+		}
 		return;
 	}
-	const uint8_t *cs = w.cs + fr.cs_off;
-	const uint32_t *seg_start = w.seg_start + fr.seg_off;
-	const uint32_t nseg = min(fs.nseg, fr.seg_cap - 1);
-	JhSubInfo *truth = w.sub + fr.sub_off;
-	const JhSubInfo *rec = w.rec + (size_t)fr.sub_off * (KMAX + 1);
-	const uint32_t *meta = w.meta + fr.sub_off;
-	const int *onfrom = w.onfrom + fr.sub_off;
-	uint32_t *wg_exit = w.wg_exit + fr.wg_off;
-	const bool full = a.round > 0;
-
-	const uint32_t j0 = b * (uint32_t)OWN;
-	const uint32_t own_end = min(nsub, j0 + (uint32_t)OWN);
-	uint32_t r = b == 0 ? 0u : wg_exit[b - 1];
-	if (r == NONE32) {
-		atomicAdd(&fs.changed[a.round], 1u);   // the previous workgroup has no exit yet: another round
-		return;
-	}
-	for (uint32_t jn = j0; jn < own_end; ++jn) {
-		// the true parse is on chain r for sub-sequence jn
-		if (!full && r >= j0 && onfrom[r] >= 0 && (uint32_t)onfrom[r] <= jn) {
-			return;                        // joined this workgroup's canonical path: the rest is already right
-		}
-		const uint32_t m = meta[r];
-		const uint32_t steps = m & 0xffu, link = m >> 8;
-		const uint32_t d = jn - r;
-		if (r <= jn && d <= steps) {
-			truth[jn] = rec[(size_t)r * (KMAX + 1) + d];
-			if (d == steps && link != 0) {
-				r += link;
-			}
-			continue;
-		}
-		// chain r was cut before jn: decode on from the true state, then look for a stored chain again
-		DecState st;
-		if (jn == 0) {
-			state_from(st, 0ull, 0);
-		} else {
-			const JhSubInfo p = truth[jn - 1];
-			state_from(st, p.state, p.seg);
-		}
-		if (st.c >= a.g.B || st.z > 63 || st.seg > nseg) {
-			atomicAdd(&fs.changed[a.round], 1u);   // raced with a neighbour's rewrite: redo next round
-			return;
-		}
-		decode_span<false>(st, (jn + 1) * JH_SUBSEQ_BITS, GlobalStream{cs}, total_bits, seg_start, nseg, luts, tb, a.g.B, &dcs[0][threadIdx.x], 64, nullptr, 0, 0);
-		store_info(&truth[jn], st);
-		const unsigned long long key = chain_key(pack_state(st), st.seg);
-		const uint32_t lo = jn > (uint32_t)KMAX ? jn - KMAX : 0u;
-		for (uint32_t c = jn + 1; c-- > lo;) {
-			const uint32_t mc = meta[c];
-			const uint32_t dc = jn - c;
-			if (dc <= (mc & 0xffu)) {
-				const JhSubInfo x = rec[(size_t)c * (KMAX + 1) + dc];
-				if (chain_key(x.state, x.seg) == key) {
-					r = (dc == (mc & 0xffu) && (mc >> 8) != 0) ? c + (mc >> 8) : c;
-					break;
-				}
+	Agg carry = agg_identity();
+	for (uint32_t b0 = 0; b0 < nwg; b0 += 64) {
+		const uint32_t b = b0 + threadIdx.x;
+		Agg v = agg_identity();
+		if (b < nwg) {
+			const JhWgAgg g = w.wg_agg[fr.wg_off + b];
+			v.nb = g.nb;
+			v.rs = (g.flags & JH_AGG_RESET) ? 1 : 0;
+#pragma unroll
+			for (int k = 0; k < JH_MAX_COMP; ++k) {
+				v.dc[k] = g.dc[k];
 			}
 		}
+		Agg incl, excl;
+		wave_seg_scan(v, incl, excl);
+		const Agg e = agg_combine(carry, excl);
+		if (b < nwg) {
+			JhWgAgg o;
+			o.nb = e.nb;
+			o.flags = e.rs ? (uint32_t)JH_AGG_RESET : 0u;
+#pragma unroll
+			for (int k = 0; k < JH_MAX_COMP; ++k) {
+				o.dc[k] = e.dc[k];
+			}
+			o.next_seed = JH_SEED_NONE;
+			o.pad = 0;
+			w.wg_base[fr.wg_off + b] = o;
+		}
+		Agg last;
+		last.nb = __shfl(incl.nb, 63, 64);
+		last.rs = __shfl(incl.rs, 63, 64);
+#pragma unroll
+		for (int k = 0; k < JH_MAX_COMP; ++k) {
+			last.dc[k] = __shfl(incl.dc[k], 63, 64);
+		}
+		carry = agg_combine(carry, last);
 	}
-	if (own_end < nsub && wg_exit[b] != r) {
-		wg_exit[b] = r;
-		atomicAdd(&fs.changed[a.round], 1u);
+	if (threadIdx.x == 0) {
+		fs.nblocks = (uint32_t)carry.nb;
 	}
 }
 
-int jh_launch_huff_sync(const JhDecodeWork &w, const JhGeom &g, hipStream_t s, bool resync_only, const JhTimerHook *th)
+int jh_launch_huff_sync(const JhDecodeWork &w, const JhGeom &g, hipStream_t s, const JhTimerHook *th)
 {
 	HuffArgs a;
 	a.w = w;
@@ -365,25 +745,22 @@ int jh_launch_huff_sync(const JhDecodeWork &w, const JhGeom &g, hipStream_t s, b
 	a.round = 0;
 	const size_t lds = sizeof(JhHuffLut) * (size_t)w.max_luts;
 	const size_t lds_chains = lds + JH_STREAM_LDS_WORDS(256) * sizeof(uint32_t);
-	const unsigned nwg = (w.max_subs + OWN - 1) / OWN;
-	if (!resync_only) {
-		// static + dynamic LDS of this kernel exceeds the 64 KB default limit
-		if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_huff_chains), hipFuncAttributeMaxDynamicSharedMemorySize,
-		                        (int)lds_chains) != hipSuccess) {
-			return -1;
-		}
-		JH_T_BEGIN(th, "k_huff_chains", s);
-		hipLaunchKernelGGL(k_huff_chains, dim3(nwg, w.nframes), dim3(256), lds_chains, s, a);
-		JH_T_END(th, s);
+	const unsigned nwg = jh_num_chain_wgs(w.max_subs);
+	// static + dynamic LDS of this kernel exceeds the 64 KB default limit
+	if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_huff_chains), hipFuncAttributeMaxDynamicSharedMemorySize,
+	                        (int)lds_chains) != hipSuccess) {
+		return -1;
 	}
-	JH_T_BEGIN(th, "k_huff_fix", s);
-	for (int r = 0; r < JH_SYNC_ITERS; ++r) {
-		a.round = resync_only ? r + 1 : r;                // a resync continues with full walks
-		if (a.round > JH_SYNC_ITERS) {
-			break;
-		}
-		hipLaunchKernelGGL(k_huff_fix, dim3((nwg + 63) / 64, w.nframes), dim3(64), lds, s, a);
+	JH_T_BEGIN(th, "k_huff_chains", s);
+	hipLaunchKernelGGL(k_huff_chains, dim3(nwg, w.nframes), dim3(256), lds_chains, s, a);
+	JH_T_END(th, s);
+	JH_T_BEGIN(th, "k_huff_repair", s);
+	if (nwg > 1) {
+		hipLaunchKernelGGL(k_huff_repair, dim3(nwg - 1, w.nframes), dim3(256), 0, s, a);
 	}
+	JH_T_END(th, s);
+	JH_T_BEGIN(th, "k_huff_finish", s);
+	hipLaunchKernelGGL(k_huff_finish, dim3(1, w.nframes), dim3(64), lds, s, a);
 	JH_T_END(th, s);
 	return hipGetLastError() == hipSuccess ? 0 : -1;
 }

@@ -34,7 +34,7 @@ struct JhDecFrame {               // written by the host in prepare()
 
 enum {                            // JhDecState.status bits
 	JH_ST_SEG_OVERFLOW = 1,       // more restart segments than reserved
-	JH_ST_NOT_CONVERGED = 2,      // speculative decode needs more synchronisation rounds
+	JH_ST_SERIAL = 2,             // the parallel synchronisation gave up on this frame: serial walk used
 };
 
 struct JhDecState {               // written by the device
@@ -42,8 +42,8 @@ struct JhDecState {               // written by the device
 	uint32_t cs_len;              // bytes of unstuffed entropy-coded data
 	uint32_t nseg;                // restart segments
 	uint32_t status;
-	uint32_t changed[JH_SYNC_ITERS + 1];
 	uint32_t nblocks;             // blocks decoded (for diagnostics)
+	uint32_t nrepaired;           // chains workgroups re-emitted by k_huff_repair (for diagnostics)
 	uint32_t term_marker;         // second byte of the marker at term_pos (0xd9 = EOI)
 };
 
@@ -52,12 +52,11 @@ struct JhDecodeWork {             // device pointers of one decoder batch
 	uint8_t *cs;                  // unstuffed streams
 	uint32_t *seg_start;          // byte offset of every restart segment inside cs (per frame slices)
 	uint32_t *chunk_kept, *chunk_rst;
-	JhSubInfo *sub;               // TRUE exit record of every sub-sequence
 	JhSubInfo *rec;               // [sub-sequence t][step d <= JH_CHAIN_MAX]: chain t after sub-sequence t + d
-	uint32_t *meta;               // per chain: steps walked | (link distance << 8), 0 = cut
-	int *onfrom;                  // per chain: first sub-sequence it carries on its workgroup's canonical path, or -1
-	uint32_t *wg_exit;            // per workgroup: chain that carries the true parse into the next one
-	JhSubStart *start;            // entry records for the write pass
+	uint32_t *meta;               // per chain: steps walked | (link distance << 8) | restarted-after-garbage << 31
+	JhWgAgg *wg_agg;              // per chains workgroup: totals of its emitted range, flags, seed of the next one
+	JhWgAgg *wg_base;             // per chains workgroup: exclusive prefix of the totals
+	JhSubStart *start;            // entry records for the write pass (relative to the workgroup's base)
 	const JhDecFrame *frames;
 	JhDecState *state;
 	const JhHuffLut *luts;
@@ -66,11 +65,12 @@ struct JhDecodeWork {             // device pointers of one decoder batch
 	uint32_t max_chunks;          // per frame (grid size)
 	uint32_t max_subs;            // per frame (grid size)
 	uint32_t max_luts;            // Huffman tables of the frame that uses most (LDS size)
+	int debug;                    // bit 0: force repairs, bit 1: force the serial walk (tests)
 };
 
 int jh_launch_ecs_unstuff(const JhDecodeWork &w, hipStream_t s, const JhTimerHook *th);
-int jh_launch_huff_sync(const JhDecodeWork &w, const JhGeom &g, hipStream_t s, bool resync_only, const JhTimerHook *th);
-int jh_launch_huff_decode(const JhDecodeWork &w, const JhGeom &g, hipStream_t s, int extra_sync_rounds, const JhTimerHook *th);
+int jh_launch_huff_sync(const JhDecodeWork &w, const JhGeom &g, hipStream_t s, const JhTimerHook *th);
+int jh_launch_huff_decode(const JhDecodeWork &w, const JhGeom &g, hipStream_t s, const JhTimerHook *th);
 
 int jh_launch_decode_pixels(const JhGeom &g, int nframes, const int16_t *coefs, const JhQuant *quant,
                             void *out, size_t frame_stride, hipStream_t stream);

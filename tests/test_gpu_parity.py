@@ -195,3 +195,51 @@ def test_roundtrip_property_full_size_4k(hip, oracle):
     err, opx, _ = oracle.decode(jpgs[0])
     assert np.array_equal(px, opx)
     d.close()
+
+
+def test_sync_paths_agree_on_a_multi_workgroup_stream(hip, oracle):
+    """The three ways the speculative decoder can settle a workgroup's entry -- verified default
+    seed, repair from the predecessor's carrier chain, serial walk -- give the same coefficients
+    and samples as the oracle.  The stream spans dozens of chains workgroups."""
+    img = synth_image(1920, 1088, 3, 8, seed=21)
+    for (H, V, ri) in [(2, 2, 0), (2, 1, 0), (1, 1, 120)]:
+        err, jpg, _ = oracle.encode(img, P=8, H=H, V=V, q=92, optimize=0, restart_interval=ri)
+        assert err == 0
+        err, opx, oinfo = oracle.decode(jpg)
+        assert err == 0
+        seen = []
+        for dbg in (0, 1, 2):
+            d = hip.Decoder()
+            d.prepare([jpg, jpg])
+            d.set_debug(dbg)
+            out = d.run()
+            assert d.sync() == [0, 0]
+            seen.append(d.stats(1))
+            _assert_coefs(d.coefficients(1), oinfo)
+            for px in d.to_arrays(out):
+                assert np.array_equal(px, opx)
+            d.close()
+        assert seen[0][0] == 0                           # fast path: no serial walk on a sane stream
+        assert seen[1][1] > 0 or seen[1][0] == 1         # forced: workgroups really were repaired
+        assert seen[2][0] == 1                           # forced: the serial walk really ran
+        assert seen[0][2] == seen[1][2] == seen[2][2]    # same number of blocks decoded
+
+
+def test_garbage_in_the_entropy_coded_data(hip, oracle):
+    """Corrupt entropy-coded data (the true parse itself hits an undecodable code): whatever path the
+    decoder takes, every MCU the reference decodes before the damage is identical and the status
+    matches."""
+    img = synth_image(640, 480, 3, 8, seed=5)
+    _, jpg, _ = oracle.encode(img, P=8, H=2, V=2, q=90, optimize=0)
+    bad = bytearray(jpg)
+    mid = len(bad) // 2
+    bad[mid:mid + 64] = b"\xff\x00" * 32              # a long run of 1-bits: no code matches
+    bad = bytes(bad)
+    err, opx, oinfo = oracle.decode(bad)
+    outs, st = hip.decode([bad])
+    assert st == [err]
+    if err == 0:
+        m_x = oinfo.m_x
+        rows = (oinfo.mblocks // m_x) * 16
+        assert rows > 0
+        assert np.array_equal(outs[0][:rows], opx[:rows])

@@ -30,6 +30,10 @@ def main():
     pix = cfg["X"] * cfg["Y"] * F
     td = bench.timed(torch, lambda: dec.run(out), 10, 2, None) / 10
     te = bench.timed(torch, lambda: enc.run(samples), 10, 2, None) / 10
+    dec.sync()
+    stats = [dec.stats(f) for f in range(F)]
+    print("stats (serial, repaired, blocks, segments):", stats[:4], "serial frames", sum(s[0] for s in stats),
+          "repaired wgs", sum(s[1] for s in stats))
     print(json.dumps({"config": name, "frames": F, "jpg_bytes": len(jpgs[0]),
                       "decode_ms": round(td * 1e3, 4), "encode_ms": round(te * 1e3, 4),
                       "decode_gpix_s": round(pix / td / 1e9, 2), "encode_gpix_s": round(pix / te / 1e9, 2),
