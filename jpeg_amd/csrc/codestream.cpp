@@ -167,6 +167,11 @@ int jh_build_declut(const JhHuffSpec *s, int tc, JhHuffLut *lut)
 			}
 		}
 	}
+	for (unsigned i = 0; i < (1u << JH_LUT_BITS); ++i) {
+		if (lut->fast[i] == 0) {
+			lut->fast[i] = (uint16_t)JH_LUT_INVALID;           // no code starts with these bits
+		}
+	}
 	// slow path: left-aligned upper limits per length (canonical MAXCODE of F.2.2.3)
 	uint32_t lim = 0;
 	for (int len = 1, p = 0; len <= 16; ++len) {

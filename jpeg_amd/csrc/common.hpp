@@ -26,12 +26,14 @@
 
 #define JH_SUB_TABLES 8               // second-level tables (64 entries) per Huffman table
 #define JH_LUT_SEARCH 0xffffu         // first-level entry: more long-code prefixes than second-level tables
+#define JH_LUT_INVALID 0xfffeu        // first-level entry: no code starts with these bits
 
 // One Huffman table, decoder view (Annex C / F.2.2.3).  Entry format of fast[] and sub[][]:
 //   bit 15 = 0: (total << 10) | (run << 4) | category, total = code length + category (<= 31),
-//               run = zero run, 63 for the EOB of an AC table; 0 = no code matches
+//               run = zero run, 63 for the EOB of an AC table; sub[][]: 0 = no code matches
 //   bit 15 = 1 (fast[] only): the code is longer than JH_LUT_BITS bits; the low bits name the
-//               second-level table indexed by the next 6 bits, JH_LUT_SEARCH = canonical search
+//               second-level table indexed by the next 6 bits, JH_LUT_SEARCH = canonical search,
+//               JH_LUT_INVALID = no code matches
 struct JhHuffLut {
 	uint16_t fast[1 << JH_LUT_BITS];
 	uint16_t sub[JH_SUB_TABLES][64];

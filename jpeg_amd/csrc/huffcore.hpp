@@ -78,14 +78,54 @@ __device__ __forceinline__ void stage_stream(uint32_t *sw, const uint8_t *cs, ui
 // of a select chain over four registers
 #define DCS_AT(dcs, k, stride) ((dcs)[(k) * (stride)])
 
+__device__ __forceinline__ uint32_t bit_window(uint32_t w0, uint32_t w1, uint32_t pos)
+{
+	return (uint32_t)((((unsigned long long)w0 << 32 | w1) << (pos & 31u)) >> 32);
+}
+
+// F.12: extend the sign of a cat-bit magnitude field (coeffs.c:33-48); cat == 0 gives 0
+__device__ __forceinline__ int extend_sign(unsigned extra, int cat)
+{
+	return (int)extra - ((extra >> ((cat - 1) & 31)) ? 0 : (1 << cat) - 1);
+}
+
+// resolves a first-level entry with bit 15 set: second-level table, canonical search, or 0 = no code
+__device__ __forceinline__ unsigned long_code(const unsigned char *tab, unsigned e, uint32_t win, bool isdc)
+{
+	const JhHuffLut *L = reinterpret_cast<const JhHuffLut *>(tab);
+	if (e == JH_LUT_INVALID) {
+		return 0;
+	}
+	if (e != JH_LUT_SEARCH) {
+		return L->sub[e & 0x7fffu][(win >> (26 - JH_LUT_BITS)) & 63u];
+	}
+	// canonical search on the left-aligned 16-bit window (more prefixes than second-level tables)
+	const unsigned v = win >> 16;
+	int len = JH_LUT_BITS + 1;
+#pragma unroll
+	for (int l = JH_LUT_BITS + 1; l < 16; ++l) {
+		len += v >= L->limit[l] ? 1 : 0;
+	}
+	if (v >= L->limit[16]) {
+		return 0;
+	}
+	const unsigned sym = L->huffval[(L->offs[len] + (int)(v >> (16 - len))) & 0xff];
+	const unsigned cat = sym & 15u;
+	const unsigned run = (!isdc && sym == 0) ? 63u : (sym >> 4);   // EOB (coeffs.c:241-243)
+	return (((unsigned)len + cat) << 10) | (run << 4) | cat;
+}
+
 // Decode every symbol that STARTS before bit `stop`, beginning at st.pos.  WRITE selects the final
 // pass (coefficients stored, st.dc = predictors, blk = index of the block in progress).
 //
-// The hot loop is branch-free apart from three rarely taken exits (long code, end of a restart
-// segment, coefficient store): three stream words are kept in registers (w0:w1 hold the current
-// bit, w2 is the word after them, re-read every iteration so that it is there before a word
-// boundary is crossed), and the tables of the NEXT block of the MCU are fetched while the current
-// block is still being decoded.
+// Two regions.  FAST: symbols that start at least 31 bits before the end of the restart segment cannot
+// run past it, so the loop needs no end-of-segment test; it is software-pipelined by hand -- the
+// table look-up of the NEXT symbol is issued as soon as the current symbol's length is known, the
+// value extraction and the bookkeeping of the current symbol run in its shadow -- and branch-free
+// apart from the rare long code and the coefficient store.  Three stream words are kept in registers
+// (w0:w1 hold the current bit, w2 the word after them, re-read every iteration), and the tables of the
+// next block of the MCU are fetched while the current block is being decoded.  CAREFUL: one symbol
+// with every test of the reference's read_block(), used near segment ends and for undecodable data.
 template <bool WRITE, class Stream>
 __device__ __forceinline__ void decode_span(DecState &st, const uint32_t stop, const Stream &S,
                                             const uint32_t total_bits, const uint32_t *seg_start,
@@ -103,108 +143,138 @@ __device__ __forceinline__ void decode_span(DecState &st, const uint32_t stop, c
 	uint32_t seg_end = min(seg_start[st.seg + 1] * 8u, total_bits);
 	uint32_t pos = st.pos;
 	int c = st.c, z = st.z, nb = st.nb;
-	int cn = (c + 1 == B) ? 0 : c + 1;
-	uint32_t info = tb.info[c], info_n = tb.info[cn];
-	uint32_t wi = pos >> 5;
-	uint32_t w0 = S.word(wi), w1 = S.word(wi + 1), w2 = S.word(wi + 2);
 
-	while (pos < stop) {
-		const uint32_t win = (uint32_t)((((unsigned long long)w0 << 32 | w1) << (pos & 31u)) >> 32);
-		const bool isdc = z == 0;
-		const unsigned char *lut = luts + (((info >> (isdc ? 0 : 12)) & 0xfffu) << 4);
-		unsigned e = reinterpret_cast<const uint16_t *>(lut)[win >> (32 - JH_LUT_BITS)];
-		if (e & 0x8000u) {
-			// code longer than the fast table
-			const JhHuffLut *L = reinterpret_cast<const JhHuffLut *>(lut);
-			if (e != JH_LUT_SEARCH) {
-				e = L->sub[e & 0x7fffu][(win >> (26 - JH_LUT_BITS)) & 63u];
-			} else {
-				// canonical search on the left-aligned 16-bit window (more prefixes than second-level tables)
-				const unsigned v = win >> 16;
-				int len = JH_LUT_BITS + 1;
-#pragma unroll
-				for (int l = JH_LUT_BITS + 1; l < 16; ++l) {
-					len += v >= L->limit[l] ? 1 : 0;
+	for (;;) {
+		// ------------------------------------------------------------------------------ fast
+		const uint32_t fast_stop = min(stop, seg_end > 31u ? seg_end - 31u : 0u);
+		if (pos < fast_stop) {
+			int cn = (c + 1 == B) ? 0 : c + 1;
+			uint32_t info = tb.info[c], info_n = tb.info[cn];
+			const unsigned char *tac = luts + (((info >> 12) & 0xfffu) << 4);
+			int *dca = dcs + (info >> 24) * dcs_stride;
+			uint32_t wi = pos >> 5;
+			uint32_t w0 = S.word(wi), w1 = S.word(wi + 1), w2 = S.word(wi + 2);
+			uint32_t win = bit_window(w0, w1, pos);
+			const unsigned char *tab = z == 0 ? luts + ((info & 0xfffu) << 4) : tac;
+			unsigned e = reinterpret_cast<const uint16_t *>(tab)[win >> (32 - JH_LUT_BITS)];
+			do {
+				const bool isdc = z == 0;
+				if (e & 0x8000u) {
+					e = long_code(tab, e, win, isdc);
+					if (e == 0) {
+						break;                 // no code matches: the careful path ends the segment
+					}
 				}
-				e = 0;
-				if (v < L->limit[16]) {
-					const unsigned sym = L->huffval[(L->offs[len] + (int)(v >> (16 - len))) & 0xff];
-					const unsigned cat = sym & 15u;
-					const unsigned run = (!isdc && sym == 0) ? 63u : (sym >> 4);   // EOB (coeffs.c:241-243)
-					e = (((unsigned)len + cat) << 10) | (run << 4) | cat;
+				const int total = (int)(e >> 10), run = (int)((e >> 4) & 63u), cat = (int)(e & 15u);
+				const uint32_t npos = pos + (uint32_t)total;
+				const int k = z + run;                              // zero run (coeffs.c:246)
+				const bool done = k >= 63;
+				// the next symbol: its table, its window, its look-up
+				const unsigned char *tdc_n = luts + ((info_n & 0xfffu) << 4);
+				const unsigned char *tabn = done ? tdc_n : tac;
+				const uint32_t nwi = npos >> 5;
+				const bool cross = nwi != wi;                       // a symbol has at most 31 bits
+				w0 = cross ? w1 : w0;
+				w1 = cross ? w2 : w1;
+				wi = nwi;
+				const uint32_t nwin = bit_window(w0, w1, npos);
+				const unsigned en = reinterpret_cast<const uint16_t *>(tabn)[nwin >> (32 - JH_LUT_BITS)];
+				w2 = S.word(wi + 2);
+				// the current symbol's value
+				const unsigned extra = __builtin_amdgcn_ubfe(win, 32u - (unsigned)total, (unsigned)cat);
+				int val = extend_sign(extra, cat);
+				if (WRITE) {
+					const int old = atomicAdd(dca, isdc ? val : 0); // DC un-prediction (decoder.c:351-355)
+					val += isdc ? old : 0;
+					if ((isdc || cat != 0) && k < 64 && blk >= 0 && blk < nblk) {
+						coefs[(size_t)blk * 64 + k] = (int16_t)val;
+					}
+					blk += done ? 1 : 0;
+				} else {
+					atomicAdd(dca, isdc ? val : 0);
 				}
-			}
+				// next zig-zag index / next block
+				z = done ? 0 : k + 1;
+				nb += done ? 1 : 0;
+				c = done ? cn : c;
+				tac = done ? luts + (((info_n >> 12) & 0xfffu) << 4) : tac;
+				dca = done ? dcs + (info_n >> 24) * dcs_stride : dca;
+				cn = (c + 1 == B) ? 0 : c + 1;
+				info_n = tb.info[cn];
+				pos = npos;
+				win = nwin;
+				tab = tabn;
+				e = en;
+			} while (pos < fast_stop);
 		}
-		const int total = (int)(e >> 10), run = (int)((e >> 4) & 63u), cat = (int)(e & 15u);
-		const uint32_t npos = pos + (uint32_t)total;
-		if (e == 0 || npos > seg_end) {
-			// no code matches (the reference reads on to the end of the segment), or the data of this
-			// restart segment is used up (padding bits, truncated data): decoder.c:376-381.
-			// The MCU in progress is dropped (context->mblocks is not incremented), the next segment
-			// starts with block 0 / DC predictors 0 (decoder.c:369-373).
-			nb -= c;
-			if (WRITE) {
-				blk -= c;
+		if (pos >= stop) {
+			break;
+		}
+		// --------------------------------------------------------------------------- careful
+		{
+			const uint32_t info = tb.info[c];
+			const bool isdc = z == 0;
+			const unsigned char *tab = luts + (((info >> (isdc ? 0 : 12)) & 0xfffu) << 4);
+			const uint32_t wi = pos >> 5;
+			const uint32_t win = bit_window(S.word(wi), S.word(wi + 1), pos);
+			unsigned e = reinterpret_cast<const uint16_t *>(tab)[win >> (32 - JH_LUT_BITS)];
+			if (e & 0x8000u) {
+				e = long_code(tab, e, win, isdc);
 			}
-			c = 0;
-			z = 0;
-			cn = B == 1 ? 0 : 1;
-			info = tb.info[0];
-			info_n = tb.info[cn];
-			st.reset = 1;
+			const int total = (int)(e >> 10), run = (int)((e >> 4) & 63u), cat = (int)(e & 15u);
+			const uint32_t npos = pos + (uint32_t)total;
+			if (e == 0 || npos > seg_end) {
+				// no code matches (the reference reads on to the end of the segment), or the data of this
+				// restart segment is used up (padding bits, truncated data): decoder.c:376-381.
+				// The MCU in progress is dropped (context->mblocks is not incremented), the next segment
+				// starts with block 0 / DC predictors 0 (decoder.c:369-373).
+				nb -= c;
+				if (WRITE) {
+					blk -= c;
+				}
+				c = 0;
+				z = 0;
+				st.reset = 1;
 #pragma unroll
-			for (int k = 0; k < JH_MAX_COMP; ++k) {
-				DCS_AT(dcs, k, dcs_stride) = 0;
+				for (int k = 0; k < JH_MAX_COMP; ++k) {
+					DCS_AT(dcs, k, dcs_stride) = 0;
+				}
+				st.seg++;
+				if (st.seg >= nseg) {
+					pos = total_bits;
+					break;
+				}
+				pos = seg_end;
+				seg_end = min(seg_start[st.seg + 1] * 8u, total_bits);
+				if (pos >= stop) {
+					break;
+				}
+				continue;
 			}
-			st.seg++;
-			if (st.seg >= nseg) {
-				pos = total_bits;
-				break;
+			const unsigned extra = __builtin_amdgcn_ubfe(win, 32u - (unsigned)total, (unsigned)cat);
+			int val = extend_sign(extra, cat);
+			int *dca = dcs + (info >> 24) * dcs_stride;
+			if (isdc) {
+				val += atomicAdd(dca, val);
 			}
-			pos = seg_end;
-			seg_end = min(seg_start[st.seg + 1] * 8u, total_bits);
+			const int k = z + run;
+			if (WRITE && (isdc || cat != 0) && k < 64 && blk >= 0 && blk < nblk) {
+				coefs[(size_t)blk * 64 + k] = (int16_t)val;
+			}
+			pos = npos;
+			z = k + 1;
+			if (k >= 63) {
+				z = 0;
+				c = (c + 1 == B) ? 0 : c + 1;
+				nb++;
+				if (WRITE) {
+					blk++;
+				}
+			}
 			if (pos >= stop) {
 				break;
 			}
-			wi = pos >> 5;
-			w0 = S.word(wi);
-			w1 = S.word(wi + 1);
-			w2 = S.word(wi + 2);
-			continue;
 		}
-		// F.12: extend the sign of the cat-bit magnitude field that follows the code (coeffs.c:33-48)
-		const unsigned extra = __builtin_amdgcn_ubfe(win, 32u - (unsigned)total, (unsigned)cat);
-		int val = (int)extra - ((extra >> ((cat - 1) & 31)) ? 0 : (1 << cat) - 1);
-		int *dca = dcs + (info >> 24) * dcs_stride;
-		if (WRITE) {
-			const int old = atomicAdd(dca, isdc ? val : 0);     // DC un-prediction (decoder.c:351-355)
-			val += isdc ? old : 0;
-		} else {
-			atomicAdd(dca, isdc ? val : 0);
-		}
-		const int k = z + run;                                  // zero run (coeffs.c:246)
-		if (WRITE && (isdc || cat != 0) && k < 64 && blk >= 0 && blk < nblk) {
-			coefs[(size_t)blk * 64 + k] = (int16_t)val;
-		}
-		// advance the register window (a symbol is at most 31 bits: at most one word boundary)
-		const uint32_t nwi = npos >> 5;
-		const bool cross = nwi != wi;
-		w0 = cross ? w1 : w0;
-		w1 = cross ? w2 : w1;
-		wi = nwi;
-		pos = npos;
-		w2 = S.word(wi + 2);
-		// next zig-zag index / next block
-		const bool done = k >= 63;
-		z = done ? 0 : k + 1;
-		nb += done ? 1 : 0;
-		if (WRITE) {
-			blk += done ? 1 : 0;
-		}
-		c = done ? cn : c;
-		info = done ? info_n : info;
-		cn = (c + 1 == B) ? 0 : c + 1;
-		info_n = tb.info[cn];
 	}
 	st.pos = pos;
 	st.c = c;

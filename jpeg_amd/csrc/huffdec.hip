@@ -293,10 +293,15 @@ __global__ __launch_bounds__(256) void k_huff_write(const HuffArgs a)
 		return;
 	}
 	const uint8_t *cs = w.cs + fr.cs_off;
+#ifdef JH_LDS_STREAM
 	LdsStream S;
 	S.sw = sw;
 	S.wbase = blockIdx.x * 256u * (JH_SUBSEQ_BITS / 32);
 	stage_stream(sw, cs, S.wbase, min(256u, nsub - blockIdx.x * 256u) * (JH_SUBSEQ_BITS / 32) + 4);
+#else
+	(void)sw;
+	const GlobalStream S{cs};
+#endif
 	load_tables(w, fr, luts, &tb, a.g);
 	const uint32_t t = blockIdx.x * 256u + threadIdx.x;
 	if (t >= nsub) {
@@ -338,7 +343,10 @@ int jh_launch_huff_decode(const JhDecodeWork &w, const JhGeom &g, hipStream_t s,
 	a.g = g;
 	a.round = 0;
 	// one launch configuration for the batch: LDS for the largest table set of any frame
-	size_t lds = sizeof(JhHuffLut) * (size_t)w.max_luts + JH_STREAM_LDS_WORDS(256) * sizeof(uint32_t);
+	size_t lds = sizeof(JhHuffLut) * (size_t)w.max_luts;
+#ifdef JH_LDS_STREAM
+	lds += JH_STREAM_LDS_WORDS(256) * sizeof(uint32_t);
+#endif
 	dim3 gsub((w.max_subs + 255) / 256, w.nframes);
 	if (jh_launch_huff_sync(w, g, s, th)) {
 		return -1;
