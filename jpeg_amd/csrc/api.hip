@@ -289,7 +289,7 @@ extern "C" int jpeg_hip_decoder_prepare(jpeg_hip_decoder *dec, int nframes,
 		fr.raw_end = (uint32_t)(raw_off + flen);
 		const size_t ecs = flen - h.ecs_offset;
 		fr.cs_off = (uint32_t)cs_off;
-		const size_t cs_cap = align_up(ecs + 32 + 256, 64);      // staging reads a few words past the end
+		const size_t cs_cap = align_up(ecs + 32 + 1024, 64);     // staging reads some words past the end
 		fr.sub_off = (uint32_t)sub_off;
 		fr.sub_cap = (uint32_t)(cs_cap / JH_SUBSEQ_BYTES + 2);
 		fr.seg_off = (uint32_t)seg_off;
@@ -439,15 +439,10 @@ static int decoder_launch(jpeg_hip_decoder *dec, hipStream_t s)
 {
 	const JhDecodeWork &w = dec->work;
 	const JhTimerHook th = dec->timer.hook();
-	const size_t coef_bytes = (size_t)dec->nframes * dec->g.nblk * 64 * sizeof(int16_t);
 	hipLaunchKernelGGL(k_dec_init, dim3((dec->nframes + 63) / 64), dim3(64), 0, s, dec->d_state, dec->nframes);
 	if (jh_launch_ecs_unstuff(w, s, &th)) {
 		return RET_FAILURE_LOGIC_ERROR;
 	}
-	dec->timer.begin("coef_clear", s);
-	// alloc_buffers() zero-fills int_buffer (common.c:129): blocks the stream never reaches stay 0
-	HIPCHK(hipMemsetAsync(dec->d_coefs, 0, coef_bytes, s));
-	dec->timer.end(s);
 	if (jh_launch_huff_decode(w, dec->g, s, &th)) {
 		return RET_FAILURE_LOGIC_ERROR;
 	}

@@ -274,14 +274,92 @@ int jh_launch_ecs_unstuff(const JhDecodeWork &w, hipStream_t s, const JhTimerHoo
 }
 
 // ===================================================================================== 5. write pass
+//
+// Every thread re-decodes its sub-sequence from its now-known entry state.  Coefficients go to HBM
+// as WHOLE 128-byte blocks, each written exactly once: a thread collects the block it is decoding in
+// its own 128-byte LDS buffer; when blocks complete, the wave flushes them together, 8 lanes per
+// block with one 16-byte store each (a full cache line per block, no partial-line traffic, no
+// separate zero-fill of the coefficient buffer).  A block that straddles a sub-sequence boundary
+// belongs to the thread in whose sub-sequence it STARTS: that thread decodes on past its boundary
+// until the block is complete, the next thread discards what it decodes before its first block start.
 
-__global__ __launch_bounds__(256) void k_huff_write(const HuffArgs a)
+#define WR_THREADS 512
+#define WR_EXTRA_WORDS 68             // staged past the workgroup's last sub-sequence (blocks that run over)
+
+// chains workgroup that emitted the entry record of sub-sequence t (huffsync.hip)
+__device__ __forceinline__ uint32_t chain_wg_of(uint32_t t)
+{
+	return t < 256u ? 0u : (t - JH_CHAIN_MAX) / JH_SEQ_OWN;
+}
+
+struct WrEntry {
+	uint32_t pos, seg;
+	int c, z, blk;
+	int dc[JH_MAX_COMP];
+};
+
+// entry record: relative to the chains workgroup that emitted it, plus that workgroup's base.
+// blocks: plain sum (the reference's mblocks counter runs across restart markers, decoder.c:381);
+// DC predictors: back to 0 at every restart boundary (decoder.c:371-373)
+__device__ __forceinline__ WrEntry load_entry(const JhDecodeWork &w, const JhDecFrame &fr, uint32_t t)
+{
+	const JhSubStart s0 = w.start[fr.sub_off + t];
+	const JhWgAgg base = w.wg_base[fr.wg_off + chain_wg_of(t)];
+	const bool cut = (s0.state >> 48) & 1;
+	WrEntry e;
+	e.pos = (uint32_t)(s0.state & 0xffffffffu);
+	e.c = (int)((s0.state >> 32) & 0xff);
+	e.z = (int)((s0.state >> 40) & 0xff);
+	e.seg = s0.seg;
+	e.blk = base.nb + s0.blk;
+#pragma unroll
+	for (int k = 0; k < JH_MAX_COMP; ++k) {
+		e.dc[k] = cut ? s0.pred[k] : base.dc[k] + s0.pred[k];
+	}
+	return e;
+}
+
+// The wave writes the blocks its lanes completed in this iteration.  fin: this lane completed a block;
+// fblk: its index in the frame, or -1 = discard (not this lane's block).  bufs = the workgroup's block
+// buffers as 16-byte chunks, buffer of thread i = chunks [8 i, 8 i + 8), logical chunk j of thread i at
+// physical position (j + i) & 7.  The flushed buffers are zeroed for the next block.
+__device__ __forceinline__ void flush_blocks(bool fin, int fblk, int4 *bufs, int4 *frame_coefs)
+{
+	const unsigned long long m = __ballot(fin);
+	if (m == 0) {
+		return;
+	}
+	const int lane = threadIdx.x & 63;
+	const int below = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+	const int n = __popcll(m);
+	// a permutation of the lanes: the r-th finished lane hands its (block, thread) to lane r
+	const int dst = fin ? below : n + (lane - below);
+	const int pblk = __builtin_amdgcn_ds_permute(dst << 2, fblk);
+	const int pthr = __builtin_amdgcn_ds_permute(dst << 2, (int)threadIdx.x);
+	for (int base = 0; base < n; base += 8) {
+		const int g = base + (lane >> 3);
+		const int sblk = __builtin_amdgcn_ds_bpermute(g << 2, pblk);
+		const int sthr = __builtin_amdgcn_ds_bpermute(g << 2, pthr);
+		if (g < n) {
+			const int phys = lane & 7;
+			int4 *src = bufs + sthr * 8 + phys;
+			const int4 v = *src;
+			*src = make_int4(0, 0, 0, 0);
+			if (sblk >= 0) {
+				frame_coefs[(size_t)sblk * 8 + ((phys - sthr) & 7)] = v;
+			}
+		}
+	}
+}
+
+__global__ __launch_bounds__(WR_THREADS) void k_huff_write(const HuffArgs a)
 {
 	extern __shared__ __align__(16) unsigned char smem[];
 	unsigned char *luts = smem;
 	uint32_t *sw = reinterpret_cast<uint32_t *>(smem + sizeof(JhHuffLut) * a.w.max_luts);
+	int4 *bufs = reinterpret_cast<int4 *>(sw + JH_STREAM_LDS_WORDS(WR_THREADS) + WR_EXTRA_WORDS + 64);
 	__shared__ DecTables tb;
-	__shared__ int dcs[JH_MAX_COMP][256];
+	__shared__ int dcs_all[JH_MAX_COMP][WR_THREADS];
 
 	const JhDecodeWork &w = a.w;
 	const int f = blockIdx.y;
@@ -289,51 +367,211 @@ __global__ __launch_bounds__(256) void k_huff_write(const HuffArgs a)
 	const JhDecState fs = w.state[f];
 	const uint32_t total_bits = fs.cs_len * 8u;
 	const uint32_t nsub = (total_bits + JH_SUBSEQ_BITS - 1) / JH_SUBSEQ_BITS;
-	if (blockIdx.x * 256u >= nsub) {
+	const uint32_t t0 = blockIdx.x * (uint32_t)WR_THREADS;
+	if (t0 >= nsub) {
 		return;
 	}
+	const int tid = threadIdx.x;
 	const uint8_t *cs = w.cs + fr.cs_off;
-#ifdef JH_LDS_STREAM
 	LdsStream S;
 	S.sw = sw;
-	S.wbase = blockIdx.x * 256u * (JH_SUBSEQ_BITS / 32);
-	stage_stream(sw, cs, S.wbase, min(256u, nsub - blockIdx.x * 256u) * (JH_SUBSEQ_BITS / 32) + 4);
-#else
-	(void)sw;
-	const GlobalStream S{cs};
-#endif
-	load_tables(w, fr, luts, &tb, a.g);
-	const uint32_t t = blockIdx.x * 256u + threadIdx.x;
-	if (t >= nsub) {
-		return;
+	S.wbase = t0 * (JH_SUBSEQ_BITS / 32);
+	const uint32_t staged = min((uint32_t)WR_THREADS, nsub - t0) * (JH_SUBSEQ_BITS / 32) + WR_EXTRA_WORDS;
+	stage_stream(sw, cs, S.wbase, staged);
+	const GlobalStream G{cs};
+#pragma unroll
+	for (int j = 0; j < 8; ++j) {
+		bufs[tid * 8 + j] = make_int4(0, 0, 0, 0);
 	}
+	load_tables(w, fr, luts, &tb, a.g);              // ends with a barrier
+
+	const uint32_t t = t0 + tid;
 	const uint32_t *seg_start = w.seg_start + fr.seg_off;
 	const uint32_t nseg = min(fs.nseg, fr.seg_cap - 1);
-	// entry record: relative to the chains workgroup that emitted it (huffsync.hip), plus that
-	// workgroup's base.  blocks: plain sum (the reference's mblocks counter runs across restart markers,
-	// decoder.c:381); DC predictors: back to 0 at every restart boundary (decoder.c:371-373)
-	const JhSubStart s0 = w.start[fr.sub_off + t];
-	const uint32_t cb = t < 256u ? 0u : (t - JH_CHAIN_MAX) / JH_SEQ_OWN;
-	const JhWgAgg base = w.wg_base[fr.wg_off + cb];
-	const bool cut = (s0.state >> 48) & 1;
+	const int B = a.g.B, nblk = a.g.nblk;
+	int4 *frame_coefs = reinterpret_cast<int4 *>(w.coefs + (size_t)f * nblk * 64);
+	int16_t *mybuf = reinterpret_cast<int16_t *>(bufs + tid * 8);
+	int *dcs = &dcs_all[0][tid];
 
-	DecState st;
-	st.pos = (uint32_t)(s0.state & 0xffffffffu);
-	st.c = (int)((s0.state >> 32) & 0xff);
-	st.z = (int)((s0.state >> 40) & 0xff);
-	st.seg = s0.seg;
-	st.reset = 0;
-	st.nb = 0;
+	// ---- entry of this thread and of the next one -------------------------------------------------
+	bool act = t < nsub;
+	uint32_t pos = 0, seg = 0, seg_end = 0;
+	int c = 0, z = 0, blk = 0;
+	int limit_blk = 0x7fffffff;                      // blocks from this index on belong to later threads
+	if (act) {
+		const WrEntry e = load_entry(w, fr, t);
+		pos = e.pos;
+		seg = e.seg;
+		c = e.c;
+		z = e.z;
+		blk = e.blk;
 #pragma unroll
-	for (int k = 0; k < JH_MAX_COMP; ++k) {
-		st.dc[k] = cut ? s0.pred[k] : base.dc[k] + s0.pred[k];
+		for (int k = 0; k < JH_MAX_COMP; ++k) {
+			DCS_AT(dcs, k, WR_THREADS) = e.dc[k];
+		}
+		// cannot fail for records produced by decode_span
+		act = c < B && z <= 63 && seg < nseg && pos >= t * JH_SUBSEQ_BITS && pos < total_bits;
+		if (act) {
+			seg_end = min(seg_start[seg + 1] * 8u, total_bits);
+		}
+		if (t + 1 < nsub) {
+			const WrEntry e1 = load_entry(w, fr, t + 1);
+			limit_blk = e1.blk + (e1.z != 0 ? 1 : 0);
+		}
 	}
-	const int blk0 = base.nb + s0.blk;
-	if (st.c >= a.g.B || st.z > 63 || st.seg >= nseg || st.pos < t * JH_SUBSEQ_BITS) {
-		return;                        // cannot happen for records produced by decode_span
+	const uint32_t stop = (t + 1) * JH_SUBSEQ_BITS;
+	const uint32_t lds_limit = (S.wbase + staged - 4) * 32u;   // the fast path reads up to 3 words ahead
+	bool own = z == 0;                               // a thread that enters mid-block does not own that block
+	bool primed = false;
+	// fast-path registers (see decode_span)
+	int cn = 0;
+	uint32_t info_n = 0, wi = 0, w0 = 0, w1 = 0, w2 = 0, win = 0;
+	unsigned e = 0;
+	const unsigned char *tac = luts, *tab = luts;
+	int *dca = dcs;
+
+	for (;;) {
+		const bool go = act && (pos < stop || z != 0);
+		if (!__any(go)) {
+			break;
+		}
+		bool fin = false;
+		int fblk = -1;
+		if (go) {
+			const uint32_t fast_stop = min(seg_end > 31u ? seg_end - 31u : 0u, lds_limit);
+			bool slow = pos >= fast_stop;
+			bool isdc = z == 0;
+			int k = 0, cat = 0, val = 0;
+			bool done = false;
+			if (!slow) {
+				if (!primed) {
+					cn = (c + 1 == B) ? 0 : c + 1;
+					const uint32_t info = tb.info[c];
+					info_n = tb.info[cn];
+					tac = luts + (((info >> 12) & 0xfffu) << 4);
+					dca = dcs + (info >> 24) * WR_THREADS;
+					wi = pos >> 5;
+					w0 = S.word(wi);
+					w1 = S.word(wi + 1);
+					w2 = S.word(wi + 2);
+					win = bit_window(w0, w1, pos);
+					tab = isdc ? luts + ((info & 0xfffu) << 4) : tac;
+					e = reinterpret_cast<const uint16_t *>(tab)[win >> (32 - JH_LUT_BITS)];
+					primed = true;
+				}
+				if (e & 0x8000u) {
+					e = long_code(tab, e, win, isdc);
+					slow = e == 0;                 // no code matches: the careful path ends the segment
+				}
+			}
+			if (!slow) {
+				const int total = (int)(e >> 10), run = (int)((e >> 4) & 63u);
+				cat = (int)(e & 15u);
+				const uint32_t npos = pos + (uint32_t)total;
+				k = z + run;                                        // zero run (coeffs.c:246)
+				done = k >= 63;
+				// the next symbol: its table, its window, its look-up
+				const unsigned char *tabn = done ? luts + ((info_n & 0xfffu) << 4) : tac;
+				const uint32_t nwi = npos >> 5;
+				const bool cross = nwi != wi;
+				w0 = cross ? w1 : w0;
+				w1 = cross ? w2 : w1;
+				wi = nwi;
+				const uint32_t nwin = bit_window(w0, w1, npos);
+				const unsigned en = reinterpret_cast<const uint16_t *>(tabn)[nwin >> (32 - JH_LUT_BITS)];
+				w2 = S.word(wi + 2);
+				// the current symbol's value
+				const unsigned extra = __builtin_amdgcn_ubfe(win, 32u - (unsigned)total, (unsigned)cat);
+				val = extend_sign(extra, cat);
+				const int old = atomicAdd(dca, isdc ? val : 0);     // DC un-prediction (decoder.c:351-355)
+				val += isdc ? old : 0;
+				c = done ? cn : c;
+				tac = done ? luts + (((info_n >> 12) & 0xfffu) << 4) : tac;
+				dca = done ? dcs + (info_n >> 24) * WR_THREADS : dca;
+				cn = (c + 1 == B) ? 0 : c + 1;
+				info_n = tb.info[cn];
+				pos = npos;
+				win = nwin;
+				tab = tabn;
+				e = en;
+			} else {
+				// ---- careful: one symbol with every test of read_block(), stream read from global memory
+				primed = false;
+				const uint32_t info = tb.info[c];
+				const unsigned char *tb1 = luts + (((info >> (isdc ? 0 : 12)) & 0xfffu) << 4);
+				const uint32_t wj = pos >> 5;
+				const uint32_t wn = bit_window(G.word(wj), G.word(wj + 1), pos);
+				unsigned e1 = reinterpret_cast<const uint16_t *>(tb1)[wn >> (32 - JH_LUT_BITS)];
+				if (e1 & 0x8000u) {
+					e1 = long_code(tb1, e1, wn, isdc);
+				}
+				const int total = (int)(e1 >> 10), run = (int)((e1 >> 4) & 63u);
+				cat = (int)(e1 & 15u);
+				const uint32_t npos = pos + (uint32_t)total;
+				if (e1 == 0 || npos > seg_end) {
+					// end of this restart segment (decoder.c:376-381): the MCU in progress is dropped, the
+					// next segment starts with block 0 / DC predictors 0 (decoder.c:369-373)
+					blk -= c;
+					c = 0;
+					z = 0;
+					own = true;
+#pragma unroll
+					for (int q = 0; q < JH_MAX_COMP; ++q) {
+						DCS_AT(dcs, q, WR_THREADS) = 0;
+					}
+#pragma unroll
+					for (int j = 0; j < 8; ++j) {
+						bufs[tid * 8 + j] = make_int4(0, 0, 0, 0);
+					}
+					seg++;
+					if (seg >= nseg) {
+						act = false;
+					} else {
+						pos = seg_end;
+						seg_end = min(seg_start[seg + 1] * 8u, total_bits);
+					}
+					k = -1;                        // no coefficient this round
+				} else {
+					const unsigned extra = __builtin_amdgcn_ubfe(wn, 32u - (unsigned)total, (unsigned)cat);
+					val = extend_sign(extra, cat);
+					if (isdc) {
+						val += atomicAdd(dcs + (info >> 24) * WR_THREADS, val);
+					}
+					k = z + run;
+					done = k >= 63;
+					pos = npos;
+					c = done ? ((c + 1 == B) ? 0 : c + 1) : c;
+				}
+			}
+			if (k >= 0) {
+				// coefficient k of the block in progress; EOB / ZRL / runs past the end store a harmless zero
+				const int kk = min(k, 63);
+				mybuf[((((kk >> 3) + tid) & 7) << 3) + (kk & 7)] = (int16_t)((k < 64 && (isdc || cat != 0)) ? val : 0);
+				z = done ? 0 : k + 1;
+				if (done) {
+					fin = true;
+					fblk = (own && blk >= 0 && blk < nblk && blk < limit_blk) ? blk : -1;
+					own = true;
+					blk++;
+				}
+			}
+		}
+		flush_blocks(fin, fblk, bufs, frame_coefs);
 	}
-	decode_span<true>(st, (t + 1) * JH_SUBSEQ_BITS, S, total_bits, seg_start, nseg, luts, tb, a.g.B, &dcs[0][threadIdx.x], 256,
-	                  w.coefs + (size_t)f * a.g.nblk * 64, blk0, a.g.nblk);
+}
+
+// blocks the stream never reached (truncated data, frames that failed to parse) are zero, as in
+// alloc_buffers() (common.c:129); normally there is none
+__global__ __launch_bounds__(256) void k_coef_tail_clear(const HuffArgs a)
+{
+	const JhDecodeWork &w = a.w;
+	const int f = blockIdx.y;
+	const size_t nblk = (size_t)a.g.nblk;
+	const size_t first = min((size_t)w.state[f].nblocks, nblk);
+	int4 *p = reinterpret_cast<int4 *>(w.coefs + (size_t)f * nblk * 64);
+	for (size_t i = first * 8 + blockIdx.x * 256u + threadIdx.x; i < nblk * 8; i += (size_t)gridDim.x * 256u) {
+		p[i] = make_int4(0, 0, 0, 0);
+	}
 }
 
 int jh_launch_huff_decode(const JhDecodeWork &w, const JhGeom &g, hipStream_t s, const JhTimerHook *th)
@@ -342,17 +580,22 @@ int jh_launch_huff_decode(const JhDecodeWork &w, const JhGeom &g, hipStream_t s,
 	a.w = w;
 	a.g = g;
 	a.round = 0;
-	// one launch configuration for the batch: LDS for the largest table set of any frame
-	size_t lds = sizeof(JhHuffLut) * (size_t)w.max_luts;
-#ifdef JH_LDS_STREAM
-	lds += JH_STREAM_LDS_WORDS(256) * sizeof(uint32_t);
-#endif
-	dim3 gsub((w.max_subs + 255) / 256, w.nframes);
 	if (jh_launch_huff_sync(w, g, s, th)) {
 		return -1;
 	}
+	// one launch configuration for the batch: LDS for the largest table set of any frame
+	const size_t lds = sizeof(JhHuffLut) * (size_t)w.max_luts +
+	                   (JH_STREAM_LDS_WORDS(WR_THREADS) + WR_EXTRA_WORDS + 64) * sizeof(uint32_t) + (size_t)WR_THREADS * 128;
+	if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_huff_write), hipFuncAttributeMaxDynamicSharedMemorySize,
+	                        (int)lds) != hipSuccess) {
+		return -1;
+	}
+	dim3 gsub((w.max_subs + WR_THREADS - 1) / WR_THREADS, w.nframes);
 	JH_T_BEGIN(th, "k_huff_write", s);
-	hipLaunchKernelGGL(k_huff_write, gsub, dim3(256), lds, s, a);
+	hipLaunchKernelGGL(k_huff_write, gsub, dim3(WR_THREADS), lds, s, a);
+	JH_T_END(th, s);
+	JH_T_BEGIN(th, "k_coef_tail_clear", s);
+	hipLaunchKernelGGL(k_coef_tail_clear, dim3(64, w.nframes), dim3(256), 0, s, a);
 	JH_T_END(th, s);
 	return hipGetLastError() == hipSuccess ? 0 : -1;
 }
