@@ -81,6 +81,22 @@ def kernel_times(obj, run, torch, reps=5):
     return {k: v / reps for k, v in acc.items()}
 
 
+def pmc_traffic(kernel, frames):
+    """HBM bytes per launch of `kernel` from the newest committed rocprofv3 --pmc summary
+    (profiles/rNN_*_pmc_traffic.json: FETCH_SIZE / WRITE_SIZE passes of this same command, gfx950
+    correction applied), scaled to this run's frames per launch.  None if there is no such file."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return None
+    with open(files[-1]) as f:
+        d = json.load(f)
+    k = d.get("kernels", {}).get(kernel)
+    if not k:
+        return None
+    return int(k["hbm_bytes"] * frames / d["frames_per_launch"])
+
+
 def cpu_baseline(imgs, jpgs, cfg, budget_s=20.0):
     """The compiled reference (oracle/_ref: unmodified sources) on ONE host core: decode + encode of
     whole 4K frames, in process, files in memory/tmpfs.  Bounded sample (~10-30 s)."""
@@ -191,7 +207,7 @@ def main():
         alg_bytes = F * pix * cfg["nc"] + jpg_bytes        # W*H*Nc*s + B_jpeg per frame
         achieved = alg_bytes / (allk[dom] * 1e-3) / 1e9
         res["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                           "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                           "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(dom, F),
                            "alg_bytes_per_launch": alg_bytes, "kernel_ms": round(allk[dom], 4)}
         res["kernel_ms"] = {k: round(v, 4) for k, v in sorted(allk.items(), key=lambda kv: -kv[1])}
         res["pipeline_hbm_frac"] = {"decode": round(alg_bytes / (t_d / args.steps) / 1e9 / HBM_PEAK_GBS, 5),
