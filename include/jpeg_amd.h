@@ -118,6 +118,16 @@ void jpeg_hip_decoder_set_debug(jpeg_hip_decoder *dec, int flags);
 /* compressed bytes actually consumed per frame (entropy-coded segment incl. RSTn), for roofline accounting */
 int  jpeg_hip_decoder_ecs_bytes(const jpeg_hip_decoder *dec, size_t *ecs_len);
 
+/* ---- Motion JPEG ---------------------------------------------------------------------------
+ * "Supports Motion JPEG" in the reference means implicit Huffman tables (common.c:90-99); its
+ * process_jpeg_stream() decodes ONE SOI..EOI codestream and reports what follows as garbage
+ * (decoder.c:603-612).  This splitter finds every codestream of a concatenated stream so that the
+ * frames can be handed to jpeg_hip_decoder_prepare() in batches, or sharded over GPUs (one process
+ * per GPU, frame f -> rank by contiguous chunks; no collective on the data path).  Host only.
+ * Returns the number of frames found (may exceed cap; only the first cap are stored), -1 on bad
+ * arguments. */
+int  jpeg_hip_mjpeg_split(const uint8_t *stream, size_t len, size_t *frame_off, size_t *frame_len, int cap);
+
 /* ---- batch encoder ------------------------------------------------------------------------
  *   configure host side: read_image() set-up (encoder.c:104-152): component sampling, quality
  *             scaled Annex K.1 tables (encoder.c:38-65), default tables (mjpeg.h), workspace.

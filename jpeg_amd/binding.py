@@ -30,7 +30,7 @@ EXPORTS = [
     "jpeg_hip_decoder_info", "jpeg_hip_decoder_frame_bytes", "jpeg_hip_decoder_run",
     "jpeg_hip_decoder_sync", "jpeg_hip_decoder_get_coefficients", "jpeg_hip_decoder_set_timing",
     "jpeg_hip_decoder_get_timing", "jpeg_hip_decoder_ecs_bytes", "jpeg_hip_decoder_get_stats",
-    "jpeg_hip_decoder_set_debug",
+    "jpeg_hip_decoder_set_debug", "jpeg_hip_mjpeg_split",
     "jpeg_hip_encoder_create", "jpeg_hip_encoder_destroy", "jpeg_hip_encoder_configure",
     "jpeg_hip_encoder_info", "jpeg_hip_encoder_run", "jpeg_hip_encoder_sync",
     "jpeg_hip_encoder_get_jpeg", "jpeg_hip_encoder_device_jpeg", "jpeg_hip_encoder_get_coefficients",
@@ -99,6 +99,7 @@ def lib():
         L.jpeg_hip_decoder_get_stats.argtypes = [vp, C.c_int, C.POINTER(C.c_uint32)]
         L.jpeg_hip_decoder_set_debug.argtypes = [vp, C.c_int]
         L.jpeg_hip_decoder_set_debug.restype = None
+        L.jpeg_hip_mjpeg_split.argtypes = [C.c_char_p, sz, C.POINTER(sz), C.POINTER(sz), C.c_int]
         L.jpeg_hip_encoder_create.argtypes = [C.POINTER(vp), C.c_int]
         L.jpeg_hip_encoder_destroy.argtypes = [vp]
         L.jpeg_hip_encoder_destroy.restype = None

@@ -38,6 +38,15 @@ extern "C" int jpeg_hip_device_count(void)
 
 extern "C" const char *jpeg_hip_version(void) { return "jpeg_amd 0.1 (gfx950)"; }
 
+// host only (no device needed): frames of a Motion JPEG stream
+extern "C" int jpeg_hip_mjpeg_split(const uint8_t *stream, size_t len, size_t *frame_off, size_t *frame_len, int cap)
+{
+	if (!stream || cap < 0 || (cap > 0 && (!frame_off || !frame_len))) {
+		return -1;
+	}
+	return jh_split_stream(stream, len, frame_off, frame_len, cap);
+}
+
 static int require_device(int device)
 {
 	int n = jpeg_hip_device_count();

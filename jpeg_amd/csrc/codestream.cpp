@@ -395,6 +395,66 @@ int next_marker(Reader &r, unsigned *m)
 }
 }  // namespace
 
+// Motion JPEG: a stream of independent SOI..EOI codestreams (the reference's process_jpeg_stream()
+// handles exactly one and reports the rest as trailing garbage, decoder.c:603-612).  Segments with a
+// length field are skipped by length (an FF D9 inside an APPn payload is not an EOI); entropy-coded
+// data is scanned for the first marker that is neither a stuffed FF00 nor RSTn (io.c:247-274).
+int jh_split_stream(const uint8_t *p, size_t n, size_t *off, size_t *len, int cap)
+{
+	int count = 0;
+	size_t i = 0;
+	while (i + 1 < n) {
+		if (!(p[i] == 0xff && p[i + 1] == 0xd8)) {
+			++i;                                               // garbage between frames
+			continue;
+		}
+		const size_t start = i;
+		i += 2;
+		bool closed = false;
+		while (i + 1 < n && !closed) {
+			if (p[i] != 0xff) {
+				++i;
+				continue;
+			}
+			const unsigned m = p[i + 1];
+			if (m == 0xff) {
+				++i;                                           // fill byte
+				continue;
+			}
+			if (m == 0x00 || m == 0x01 || (m >= 0xd0 && m <= 0xd7)) {
+				i += 2;                                        // stuffed FF, TEM, RSTn: no payload
+				continue;
+			}
+			if (m == 0xd9) {
+				i += 2;
+				closed = true;
+				break;
+			}
+			if (m == 0xd8) {
+				break;                                         // a new SOI before any EOI: the frame was cut short
+			}
+			if (i + 3 >= n) {
+				i = n;
+				break;
+			}
+			const size_t seglen = ((size_t)p[i + 2] << 8) | p[i + 3];
+			i += 2 + (seglen < 2 ? 2 : seglen);                // after SOS this lands on the entropy-coded data
+		}
+		if (i > n) {
+			i = n;
+		}
+		if (!closed && !(i + 1 < n)) {
+			i = n;                                             // no EOI: the last frame runs to the end of the data
+		}
+		if (count < cap) {
+			off[count] = start;
+			len[count] = i - start;
+		}
+		++count;
+	}
+	return count;
+}
+
 int jh_parse_headers(const uint8_t *p, size_t n, JhHeader *h)
 {
 	Reader r = {p, n, 0};

@@ -1,0 +1,87 @@
+"""Motion JPEG on one or several GPUs.
+
+Every frame of a Motion JPEG stream is an independent SOI..EOI codestream -- the reference's
+process_jpeg_stream() handles exactly one (decoder.c:603-612) -- so frames shard over GPUs with no
+collective on the data path: one process per GPU, rank r of N takes the r-th contiguous chunk of
+the frame list, decodes (or encodes) it in batches on its own device and keeps the results there.
+torch.distributed (RCCL on GPUs, gloo in the CPU tests) is used only to gather a few integers per
+rank: frames, bytes, an order-independent checksum.
+
+    frames = split(stream_bytes)                 # C++ splitter in libjpeg_amd.so (host only)
+    lo, hi = shard(len(frames), rank, world)     # this rank's frames
+    for out, status in decode_batches(frames[lo:hi], batch=256): ...
+    totals = gather_stats({"frames": hi - lo, "bytes": nbytes, "checksum": cs}, dist)
+"""
+import ctypes as C
+import zlib
+
+from . import binding
+
+
+def split(stream):
+    """Frames of a concatenated JPEG stream as a list of bytes objects (order preserved)."""
+    stream = bytes(stream)
+    L = binding.lib()
+    n = L.jpeg_hip_mjpeg_split(stream, len(stream), None, None, 0)
+    if n < 0:
+        raise binding.JpegError(n, "jpeg_hip_mjpeg_split")
+    if n == 0:
+        return []
+    off = (C.c_size_t * n)()
+    ln = (C.c_size_t * n)()
+    m = L.jpeg_hip_mjpeg_split(stream, len(stream), off, ln, n)
+    assert m == n
+    return [stream[off[i]:off[i] + ln[i]] for i in range(n)]
+
+
+def shard(nframes, rank, world):
+    """Contiguous chunk [lo, hi) of rank `rank`: sizes differ by at most one frame, order preserved
+    so that concatenating the ranks' outputs in rank order gives the single-GPU output."""
+    base, extra = divmod(nframes, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def frame_checksum(data):
+    return zlib.crc32(bytes(data)) & 0xffffffff
+
+
+def combine_checksums(checksums):
+    """Order-independent checksum of checksums (sum modulo 2^61 - 1 of a mixed value)."""
+    acc = 0
+    for c in checksums:
+        acc = (acc + (c * 0x9e3779b97f4a7c15 + 0x7f4a7c15) % ((1 << 61) - 1)) % ((1 << 61) - 1)
+    return acc
+
+
+def decode_batches(frames, batch=256, device=0):
+    """Decode `frames` (same geometry) in batches on `device`; yields (uint8 tensor [n, frame_bytes]
+    resident on the device, per-frame status list)."""
+    for i in range(0, len(frames), batch):
+        part = frames[i:i + batch]
+        d = binding.Decoder(device)
+        try:
+            d.prepare(part)
+            out = d.run()
+            st = d.sync()
+        finally:
+            d.close()
+        yield out, st
+
+
+def gather_stats(local, dist=None):
+    """Sum `frames` and `bytes`, combine `checksum` over all ranks.  dist = torch.distributed module
+    with an initialised process group, or None for a single process."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return {"frames": local["frames"], "bytes": local["bytes"], "checksum": local["checksum"],
+                "per_rank": [dict(local)]}
+    import torch
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    mine = torch.tensor([local["frames"], local["bytes"], local["checksum"]], dtype=torch.int64, device=dev)
+    allv = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(allv, mine)
+    rows = [[int(x) for x in t.tolist()] for t in allv]
+    m = (1 << 61) - 1
+    return {"frames": sum(r[0] for r in rows), "bytes": sum(r[1] for r in rows),
+            "checksum": sum(r[2] for r in rows) % m,
+            "per_rank": [{"frames": r[0], "bytes": r[1], "checksum": r[2]} for r in rows]}

@@ -243,3 +243,36 @@ def test_garbage_in_the_entropy_coded_data(hip, oracle):
         rows = (oinfo.mblocks // m_x) * 16
         assert rows > 0
         assert np.array_equal(outs[0][:rows], opx[:rows])
+
+
+def test_motion_jpeg_stream_in_batches(hip, oracle):
+    """A concatenated stream (incl. DHT-less frames that rely on the implicit tables, common.c:90-99)
+    is split by the C++ splitter and decoded in batches; every frame equals the oracle's decode."""
+    from jpeg_amd import mjpeg
+    with open(golden_path("d_mjpeg_nodht_422.jpg"), "rb") as f:
+        nodht = f.read()
+    err, ref_nodht, info = oracle.decode(nodht)
+    assert err == 0
+    X, Y = ref_nodht.shape[1], ref_nodht.shape[0]
+    frames = [nodht]
+    for i in range(6):
+        img = synth_image(X, Y, 3, 8, seed=900 + i, frame=i)
+        err, j, _ = oracle.encode(img, P=8, H=2, V=1, q=85, optimize=i % 2)
+        assert err == 0
+        frames.append(j)
+    got = mjpeg.split(b"junk" + b"".join(frames))
+    assert got == frames
+    lo, hi = mjpeg.shard(len(got), 0, 1)
+    k = 0
+    sums = []
+    for out, st in mjpeg.decode_batches(got[lo:hi], batch=3):
+        assert all(s == 0 for s in st)
+        arr = out.cpu().numpy()
+        for row in arr:
+            want = oracle.decode(frames[k])[1]
+            assert np.array_equal(row.reshape(want.shape), want)
+            sums.append(mjpeg.frame_checksum(want.tobytes()))
+            k += 1
+    assert k == len(frames)
+    tot = mjpeg.gather_stats({"frames": k, "bytes": 0, "checksum": mjpeg.combine_checksums(sums)})
+    assert tot["frames"] == len(frames)
