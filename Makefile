@@ -5,7 +5,7 @@
 HIPCC    ?= /opt/rocm/bin/hipcc
 ARCH     ?= gfx950
 CSRC      = jpeg_amd/csrc
-HIPFLAGS  = -DJH_LDS_STREAM --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function -Wno-unused-value -Wno-unused-result -Iinclude
+HIPFLAGS  = --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function -Wno-unused-value -Wno-unused-result -Iinclude
 SRCS      = $(CSRC)/api.hip $(CSRC)/pixels.hip $(CSRC)/huffdec.hip $(CSRC)/huffsync.hip $(CSRC)/huffenc.hip
 OBJS      = $(SRCS:.hip=.o) $(CSRC)/codestream.o
 HDRS      = $(CSRC)/common.hpp $(CSRC)/kernels.hpp $(CSRC)/codestream.hpp $(CSRC)/huffcore.hpp $(CSRC)/dct_lut.inc include/jpeg_amd.h

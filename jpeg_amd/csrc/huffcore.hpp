@@ -17,6 +17,10 @@
 struct DecTables {                    // workgroup-shared decode context (LDS)
 	// per block of the MCU: (DC table offset / 16) | (AC table offset / 16) << 12 | component << 24
 	uint32_t info[JH_MAX_MCU_BLOCKS];
+	// the same, unpacked for the hot loop (one 16-byte read): x = byte offset of the DC table inside the
+	// LDS copy, y = of the AC table, z = byte offset of the component's DC accumulator relative to the
+	// thread's first one, w = the block that follows in the MCU
+	uint4 ent[JH_MAX_MCU_BLOCKS];
 };
 
 struct DecState {
@@ -47,6 +51,22 @@ struct LdsStream {
 		const uint32_t x = w - wbase;
 		return sw[x + (x >> 5)];
 	}
+	struct Cursor {
+		uint32_t x2;                  // index (relative to wbase) of the word after the window
+	};
+	__device__ __forceinline__ void open(Cursor &cur, uint32_t wi, uint32_t &w0, uint32_t &w1, uint32_t &w2) const
+	{
+		cur.x2 = wi + 2 - wbase;
+		w0 = word(wi);
+		w1 = word(wi + 1);
+		w2 = sw[cur.x2 + (cur.x2 >> 5)];
+	}
+	// the window moved on by one word (cross) or stayed: the word that now follows it
+	__device__ __forceinline__ uint32_t next(Cursor &cur, bool cross, uint32_t) const
+	{
+		cur.x2 += cross ? 1u : 0u;
+		return sw[cur.x2 + (cur.x2 >> 5)];
+	}
 };
 
 struct GlobalStream {
@@ -54,6 +74,66 @@ struct GlobalStream {
 	__device__ __forceinline__ uint32_t word(uint32_t w) const
 	{
 		return __builtin_bswap32(reinterpret_cast<const uint32_t *>(cs)[w]);
+	}
+};
+
+// The stream read straight from global memory by a thread that walks it sequentially: the two window
+// words plus four look-ahead words live in registers, the four after those are already in flight
+// (one 16-byte load per four words consumed, issued a full quad ahead, so its latency is never
+// exposed).  No LDS: this is what lets the synchronisation and write kernels run at full occupancy.
+struct RegStream {
+	const uint8_t *cs;
+	struct Quad {
+		uint32_t x, y, z, w;
+	};
+	struct Cursor {
+		uint32_t b, c, d;             // the words after w2
+		int nq;                       // valid words among (w2, b, c, d)
+		Quad ld;                      // the four words after d (raw byte order), in flight
+		uint32_t nxt;                 // stream word index of ld.x
+	};
+	__device__ __forceinline__ uint32_t word(uint32_t w) const
+	{
+		return __builtin_bswap32(reinterpret_cast<const uint32_t *>(cs)[w]);
+	}
+	__device__ __forceinline__ Quad load4(uint32_t w) const
+	{
+		const uint32_t *p = reinterpret_cast<const uint32_t *>(cs) + w;    // 4-byte aligned is enough
+		Quad q;
+		q.x = p[0];
+		q.y = p[1];
+		q.z = p[2];
+		q.w = p[3];
+		return q;
+	}
+	__device__ __forceinline__ void open(Cursor &cur, uint32_t wi, uint32_t &w0, uint32_t &w1, uint32_t &w2) const
+	{
+		w0 = word(wi);
+		w1 = word(wi + 1);
+		w2 = word(wi + 2);
+		cur.b = word(wi + 3);
+		cur.c = word(wi + 4);
+		cur.d = word(wi + 5);
+		cur.nq = 4;
+		cur.nxt = wi + 6;
+		cur.ld = load4(cur.nxt);
+	}
+	__device__ __forceinline__ uint32_t next(Cursor &cur, bool cross, uint32_t w2) const
+	{
+		uint32_t a = cross ? cur.b : w2;
+		cur.b = cross ? cur.c : cur.b;
+		cur.c = cross ? cur.d : cur.c;
+		cur.nq -= cross ? 1 : 0;
+		if (cur.nq == 0) {
+			a = __builtin_bswap32(cur.ld.x);
+			cur.b = __builtin_bswap32(cur.ld.y);
+			cur.c = __builtin_bswap32(cur.ld.z);
+			cur.d = __builtin_bswap32(cur.ld.w);
+			cur.nq = 4;
+			cur.nxt += 4;
+			cur.ld = load4(cur.nxt);
+		}
+		return a;
 	}
 };
 
@@ -148,19 +228,21 @@ __device__ __forceinline__ void decode_span(DecState &st, const uint32_t stop, c
 		// ------------------------------------------------------------------------------ fast
 		const uint32_t fast_stop = min(stop, seg_end > 31u ? seg_end - 31u : 0u);
 		if (pos < fast_stop) {
-			int cn = (c + 1 == B) ? 0 : c + 1;
-			uint32_t info = tb.info[c], info_n = tb.info[cn];
-			const unsigned char *tac = luts + (((info >> 12) & 0xfffu) << 4);
-			int *dca = dcs + (info >> 24) * dcs_stride;
+			const uint4 ent = tb.ent[c];
+			int cn = (int)ent.w;
+			uint4 ent_n = tb.ent[cn];
+			uint32_t tac = ent.y, dca = ent.z;
 			uint32_t wi = pos >> 5;
-			uint32_t w0 = S.word(wi), w1 = S.word(wi + 1), w2 = S.word(wi + 2);
+			typename Stream::Cursor cur;
+			uint32_t w0, w1, w2;
+			S.open(cur, wi, w0, w1, w2);
 			uint32_t win = bit_window(w0, w1, pos);
-			const unsigned char *tab = z == 0 ? luts + ((info & 0xfffu) << 4) : tac;
-			unsigned e = reinterpret_cast<const uint16_t *>(tab)[win >> (32 - JH_LUT_BITS)];
+			uint32_t tab = z == 0 ? ent.x : tac;
+			unsigned e = *reinterpret_cast<const uint16_t *>(luts + tab + ((win >> (32 - JH_LUT_BITS)) << 1));
 			do {
 				const bool isdc = z == 0;
 				if (e & 0x8000u) {
-					e = long_code(tab, e, win, isdc);
+					e = long_code(luts + tab, e, win, isdc);
 					if (e == 0) {
 						break;                 // no code matches: the careful path ends the segment
 					}
@@ -170,37 +252,37 @@ __device__ __forceinline__ void decode_span(DecState &st, const uint32_t stop, c
 				const int k = z + run;                              // zero run (coeffs.c:246)
 				const bool done = k >= 63;
 				// the next symbol: its table, its window, its look-up
-				const unsigned char *tdc_n = luts + ((info_n & 0xfffu) << 4);
-				const unsigned char *tabn = done ? tdc_n : tac;
+				const uint32_t tabn = done ? ent_n.x : tac;
 				const uint32_t nwi = npos >> 5;
 				const bool cross = nwi != wi;                       // a symbol has at most 31 bits
 				w0 = cross ? w1 : w0;
 				w1 = cross ? w2 : w1;
 				wi = nwi;
 				const uint32_t nwin = bit_window(w0, w1, npos);
-				const unsigned en = reinterpret_cast<const uint16_t *>(tabn)[nwin >> (32 - JH_LUT_BITS)];
-				w2 = S.word(wi + 2);
+				const unsigned en = *reinterpret_cast<const uint16_t *>(luts + tabn + ((nwin >> (32 - JH_LUT_BITS)) << 1));
+				w2 = S.next(cur, cross, w2);
 				// the current symbol's value
 				const unsigned extra = __builtin_amdgcn_ubfe(win, 32u - (unsigned)total, (unsigned)cat);
 				int val = extend_sign(extra, cat);
+				int *acc = reinterpret_cast<int *>(reinterpret_cast<char *>(dcs) + dca);
 				if (WRITE) {
-					const int old = atomicAdd(dca, isdc ? val : 0); // DC un-prediction (decoder.c:351-355)
+					const int old = atomicAdd(acc, isdc ? val : 0); // DC un-prediction (decoder.c:351-355)
 					val += isdc ? old : 0;
 					if ((isdc || cat != 0) && k < 64 && blk >= 0 && blk < nblk) {
 						coefs[(size_t)blk * 64 + k] = (int16_t)val;
 					}
 					blk += done ? 1 : 0;
 				} else {
-					atomicAdd(dca, isdc ? val : 0);
+					atomicAdd(acc, isdc ? val : 0);
 				}
 				// next zig-zag index / next block
 				z = done ? 0 : k + 1;
 				nb += done ? 1 : 0;
 				c = done ? cn : c;
-				tac = done ? luts + (((info_n >> 12) & 0xfffu) << 4) : tac;
-				dca = done ? dcs + (info_n >> 24) * dcs_stride : dca;
-				cn = (c + 1 == B) ? 0 : c + 1;
-				info_n = tb.info[cn];
+				tac = done ? ent_n.y : tac;
+				dca = done ? ent_n.z : dca;
+				cn = done ? (int)ent_n.w : cn;
+				ent_n = tb.ent[cn];
 				pos = npos;
 				win = nwin;
 				tab = tabn;
@@ -302,7 +384,7 @@ __device__ __forceinline__ uint32_t find_segment(const uint32_t *seg_start, uint
 }
 
 __device__ __forceinline__ void load_tables(const JhDecodeWork &w, const JhDecFrame &fr, unsigned char *luts, DecTables *tb,
-                                            const JhGeom &g)
+                                            const JhGeom &g, int dcs_stride)
 {
 	const uint32_t *src = reinterpret_cast<const uint32_t *>(w.luts + fr.lut_off);
 	uint32_t *dst = reinterpret_cast<uint32_t *>(luts);
@@ -316,6 +398,10 @@ __device__ __forceinline__ void load_tables(const JhDecodeWork &w, const JhDecFr
 		const uint32_t unit = (uint32_t)(sizeof(JhHuffLut) / 16);
 		tb->info[threadIdx.x] = gf->blk_dc[threadIdx.x] * unit | (gf->blk_ac[threadIdx.x] * unit) << 12 |
 		                        (uint32_t)g.blk_comp[threadIdx.x] << 24;
+		tb->ent[threadIdx.x] = make_uint4(gf->blk_dc[threadIdx.x] * (uint32_t)sizeof(JhHuffLut),
+		                                  gf->blk_ac[threadIdx.x] * (uint32_t)sizeof(JhHuffLut),
+		                                  (uint32_t)g.blk_comp[threadIdx.x] * (uint32_t)dcs_stride * 4u,
+		                                  (int)threadIdx.x + 1 >= g.B ? 0u : threadIdx.x + 1u);
 	}
 	__syncthreads();
 }

@@ -283,8 +283,7 @@ int jh_launch_ecs_unstuff(const JhDecodeWork &w, hipStream_t s, const JhTimerHoo
 // belongs to the thread in whose sub-sequence it STARTS: that thread decodes on past its boundary
 // until the block is complete, the next thread discards what it decodes before its first block start.
 
-#define WR_THREADS 512
-#define WR_EXTRA_WORDS 68             // staged past the workgroup's last sub-sequence (blocks that run over)
+#define WR_THREADS 256
 
 // chains workgroup that emitted the entry record of sub-sequence t (huffsync.hip)
 __device__ __forceinline__ uint32_t chain_wg_of(uint32_t t)
@@ -356,8 +355,7 @@ __global__ __launch_bounds__(WR_THREADS) void k_huff_write(const HuffArgs a)
 {
 	extern __shared__ __align__(16) unsigned char smem[];
 	unsigned char *luts = smem;
-	uint32_t *sw = reinterpret_cast<uint32_t *>(smem + sizeof(JhHuffLut) * a.w.max_luts);
-	int4 *bufs = reinterpret_cast<int4 *>(sw + JH_STREAM_LDS_WORDS(WR_THREADS) + WR_EXTRA_WORDS + 64);
+	int4 *bufs = reinterpret_cast<int4 *>(smem + sizeof(JhHuffLut) * a.w.max_luts);
 	__shared__ DecTables tb;
 	__shared__ int dcs_all[JH_MAX_COMP][WR_THREADS];
 
@@ -373,17 +371,13 @@ __global__ __launch_bounds__(WR_THREADS) void k_huff_write(const HuffArgs a)
 	}
 	const int tid = threadIdx.x;
 	const uint8_t *cs = w.cs + fr.cs_off;
-	LdsStream S;
-	S.sw = sw;
-	S.wbase = t0 * (JH_SUBSEQ_BITS / 32);
-	const uint32_t staged = min((uint32_t)WR_THREADS, nsub - t0) * (JH_SUBSEQ_BITS / 32) + WR_EXTRA_WORDS;
-	stage_stream(sw, cs, S.wbase, staged);
+	const RegStream S{cs};
 	const GlobalStream G{cs};
 #pragma unroll
 	for (int j = 0; j < 8; ++j) {
 		bufs[tid * 8 + j] = make_int4(0, 0, 0, 0);
 	}
-	load_tables(w, fr, luts, &tb, a.g);              // ends with a barrier
+	load_tables(w, fr, luts, &tb, a.g, WR_THREADS);  // ends with a barrier
 
 	const uint32_t t = t0 + tid;
 	const uint32_t *seg_start = w.seg_start + fr.seg_off;
@@ -420,15 +414,18 @@ __global__ __launch_bounds__(WR_THREADS) void k_huff_write(const HuffArgs a)
 		}
 	}
 	const uint32_t stop = (t + 1) * JH_SUBSEQ_BITS;
-	const uint32_t lds_limit = (S.wbase + staged - 4) * 32u;   // the fast path reads up to 3 words ahead
 	bool own = z == 0;                               // a thread that enters mid-block does not own that block
 	bool primed = false;
 	// fast-path registers (see decode_span)
 	int cn = 0;
-	uint32_t info_n = 0, wi = 0, w0 = 0, w1 = 0, w2 = 0, win = 0;
+	uint4 ent_n = make_uint4(0, 0, 0, 0);
+	uint32_t wi = 0, w0 = 0, w1 = 0, w2 = 0, win = 0, tac = 0, tab = 0, dca = 0;
+	RegStream::Cursor cur;
+	cur.b = cur.c = cur.d = 0;
+	cur.nq = 4;
+	cur.nxt = 0;
+	cur.ld.x = cur.ld.y = cur.ld.z = cur.ld.w = 0;
 	unsigned e = 0;
-	const unsigned char *tac = luts, *tab = luts;
-	int *dca = dcs;
 
 	for (;;) {
 		const bool go = act && (pos < stop || z != 0);
@@ -438,29 +435,27 @@ __global__ __launch_bounds__(WR_THREADS) void k_huff_write(const HuffArgs a)
 		bool fin = false;
 		int fblk = -1;
 		if (go) {
-			const uint32_t fast_stop = min(seg_end > 31u ? seg_end - 31u : 0u, lds_limit);
+			const uint32_t fast_stop = seg_end > 31u ? seg_end - 31u : 0u;
 			bool slow = pos >= fast_stop;
 			bool isdc = z == 0;
 			int k = 0, cat = 0, val = 0;
 			bool done = false;
 			if (!slow) {
 				if (!primed) {
-					cn = (c + 1 == B) ? 0 : c + 1;
-					const uint32_t info = tb.info[c];
-					info_n = tb.info[cn];
-					tac = luts + (((info >> 12) & 0xfffu) << 4);
-					dca = dcs + (info >> 24) * WR_THREADS;
+					const uint4 ent = tb.ent[c];
+					cn = (int)ent.w;
+					ent_n = tb.ent[cn];
+					tac = ent.y;
+					dca = ent.z;
 					wi = pos >> 5;
-					w0 = S.word(wi);
-					w1 = S.word(wi + 1);
-					w2 = S.word(wi + 2);
+					S.open(cur, wi, w0, w1, w2);
 					win = bit_window(w0, w1, pos);
-					tab = isdc ? luts + ((info & 0xfffu) << 4) : tac;
-					e = reinterpret_cast<const uint16_t *>(tab)[win >> (32 - JH_LUT_BITS)];
+					tab = isdc ? ent.x : tac;
+					e = *reinterpret_cast<const uint16_t *>(luts + tab + ((win >> (32 - JH_LUT_BITS)) << 1));
 					primed = true;
 				}
 				if (e & 0x8000u) {
-					e = long_code(tab, e, win, isdc);
+					e = long_code(luts + tab, e, win, isdc);
 					slow = e == 0;                 // no code matches: the careful path ends the segment
 				}
 			}
@@ -471,25 +466,26 @@ __global__ __launch_bounds__(WR_THREADS) void k_huff_write(const HuffArgs a)
 				k = z + run;                                        // zero run (coeffs.c:246)
 				done = k >= 63;
 				// the next symbol: its table, its window, its look-up
-				const unsigned char *tabn = done ? luts + ((info_n & 0xfffu) << 4) : tac;
+				const uint32_t tabn = done ? ent_n.x : tac;
 				const uint32_t nwi = npos >> 5;
 				const bool cross = nwi != wi;
 				w0 = cross ? w1 : w0;
 				w1 = cross ? w2 : w1;
 				wi = nwi;
 				const uint32_t nwin = bit_window(w0, w1, npos);
-				const unsigned en = reinterpret_cast<const uint16_t *>(tabn)[nwin >> (32 - JH_LUT_BITS)];
-				w2 = S.word(wi + 2);
+				const unsigned en = *reinterpret_cast<const uint16_t *>(luts + tabn + ((nwin >> (32 - JH_LUT_BITS)) << 1));
+				w2 = S.next(cur, cross, w2);
 				// the current symbol's value
 				const unsigned extra = __builtin_amdgcn_ubfe(win, 32u - (unsigned)total, (unsigned)cat);
 				val = extend_sign(extra, cat);
-				const int old = atomicAdd(dca, isdc ? val : 0);     // DC un-prediction (decoder.c:351-355)
+				int *acc = reinterpret_cast<int *>(reinterpret_cast<char *>(dcs) + dca);
+				const int old = atomicAdd(acc, isdc ? val : 0);     // DC un-prediction (decoder.c:351-355)
 				val += isdc ? old : 0;
 				c = done ? cn : c;
-				tac = done ? luts + (((info_n >> 12) & 0xfffu) << 4) : tac;
-				dca = done ? dcs + (info_n >> 24) * WR_THREADS : dca;
-				cn = (c + 1 == B) ? 0 : c + 1;
-				info_n = tb.info[cn];
+				tac = done ? ent_n.y : tac;
+				dca = done ? ent_n.z : dca;
+				cn = done ? (int)ent_n.w : cn;
+				ent_n = tb.ent[cn];
 				pos = npos;
 				win = nwin;
 				tab = tabn;
@@ -584,8 +580,7 @@ int jh_launch_huff_decode(const JhDecodeWork &w, const JhGeom &g, hipStream_t s,
 		return -1;
 	}
 	// one launch configuration for the batch: LDS for the largest table set of any frame
-	const size_t lds = sizeof(JhHuffLut) * (size_t)w.max_luts +
-	                   (JH_STREAM_LDS_WORDS(WR_THREADS) + WR_EXTRA_WORDS + 64) * sizeof(uint32_t) + (size_t)WR_THREADS * 128;
+	const size_t lds = sizeof(JhHuffLut) * (size_t)w.max_luts + (size_t)WR_THREADS * 128;
 	if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_huff_write), hipFuncAttributeMaxDynamicSharedMemorySize,
 	                        (int)lds) != hipSuccess) {
 		return -1;

@@ -180,7 +180,7 @@ struct PathLds {
 	uint8_t mark[256];
 	uint16_t pred[256];
 	uint8_t cov[256];
-	JhSubInfo trec[256];              // records of the marked path, by local sub-sequence
+	JhSubInfo *trec;                  // records of the marked path, by local sub-sequence (256 entries of LDS)
 	Agg scratch[4];
 	int s_last, from_last;            // path chain that covers the last sub-sequence of the range, and since where
 	int broken;
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(256) void k_huff_chains(const HuffArgs a)
 		return;
 	}
 	const uint32_t j0 = b * (uint32_t)OWN;
-	load_tables(w, fr, luts, &tb, a.g);
+	load_tables(w, fr, luts, &tb, a.g, 256);
 
 	const uint8_t *cs = w.cs + fr.cs_off;
 	const uint32_t *seg_start = w.seg_start + fr.seg_off;
@@ -362,7 +362,7 @@ __global__ __launch_bounds__(256) void k_huff_chains(const HuffArgs a)
 	stage_stream(sw, cs, S.wbase, (uint32_t)range_len * (JH_SUBSEQ_BITS / 32) + 4);
 #else
 	(void)sw;
-	const GlobalStream S{cs};
+	const RegStream S{cs};
 #endif
 	int *mydcs = &dcs[0][tid];
 
@@ -473,6 +473,11 @@ __global__ __launch_bounds__(256) void k_huff_chains(const HuffArgs a)
 	}
 
 	// ---- emit from the path of the first chain ---------------------------------------------------
+	static_assert(sizeof(dkey) >= 256 * sizeof(JhSubInfo), "the path records reuse the directory's LDS");
+	if (tid == 0) {
+		P.trec = reinterpret_cast<JhSubInfo *>(&dkey[0][0]);
+	}
+	__syncthreads();
 	const EmitResult er = emit_path(P, rec, w.start + fr.sub_off + j0, 0, 0, b == 0 ? 0 : KMAX, range_len, b == 0, need_next, &total);
 	if (tid == 0) {
 		JhWgAgg o;
@@ -500,6 +505,7 @@ __global__ __launch_bounds__(256) void k_huff_repair(const HuffArgs a)
 {
 	__shared__ PathLds P;
 	__shared__ Agg total;
+	__shared__ JhSubInfo trec_mem[256];
 
 	const JhDecodeWork &w = a.w;
 	const int f = blockIdx.y;
@@ -546,6 +552,9 @@ __global__ __launch_bounds__(256) void k_huff_repair(const HuffArgs a)
 		P.succ[tid] = su;
 		P.nst[tid] = ns;
 		P.dflag[tid] = df;
+		if (tid == 0) {
+			P.trec = trec_mem;
+		}
 	}
 	__syncthreads();
 	const int seed = (int)(prev.next_seed & 0xffu), seed_from = (int)(prev.next_seed >> 8);
@@ -652,7 +661,7 @@ __device__ void serial_walk(const HuffArgs &a, const JhDecFrame &fr, JhDecState 
 				if (st.c >= a.g.B || st.z > 63 || st.seg >= nseg) {
 					st.pos = total_bits;       // cannot happen for states produced by decode_span
 				}
-				decode_span<false>(st, (jn + 1) * JH_SUBSEQ_BITS, GlobalStream{cs}, total_bits, seg_start, nseg, luts, tb, a.g.B, dcs, 64, nullptr, 0, 0);
+				decode_span<false>(st, (jn + 1) * JH_SUBSEQ_BITS, RegStream{cs}, total_bits, seg_start, nseg, luts, tb, a.g.B, dcs, 64, nullptr, 0, 0);
 				store_info(&R, st);
 			}
 		}
@@ -694,7 +703,7 @@ __global__ __launch_bounds__(64) void k_huff_finish(const HuffArgs a)
 	}
 	const uint32_t nwg = jh_num_chain_wgs(nsub);
 	if (fs.status & JH_ST_SERIAL) {
-		load_tables(w, fr, luts, &tb, a.g);
+		load_tables(w, fr, luts, &tb, a.g, 64);
 		if (threadIdx.x == 0) {
 			serial_walk(a, fr, fs, nsub, nwg, luts, tb, &dcs[0][0]);
 		}
