@@ -109,7 +109,7 @@ int  jpeg_hip_decoder_get_coefficients(jpeg_hip_decoder *dec, int frame, int k, 
 void jpeg_hip_decoder_set_timing(jpeg_hip_decoder *dec, int on);
 int  jpeg_hip_decoder_get_timing(jpeg_hip_decoder *dec, const char **names, float *ms, int cap);
 /* Diagnostics of the speculative Huffman decoder (no counterpart in the reference, whose read_ecs()
- * is serial).  stats[0] = 1 if the frame fell back to the serial walk, stats[1] = workgroups whose
+ * is serial).  stats[0] = non-zero if the frame fell back to the serial walk (bit mask of causes), stats[1] = workgroups whose
  * entry had to be repaired, stats[2] = blocks decoded, stats[3] = restart segments.  Valid after sync().
  * set_debug: bit 0 forces the repair path on every other workgroup, bit 1 forces the serial walk
  * (tests: all three paths must give identical results). */

@@ -156,7 +156,8 @@ struct jpeg_hip_decoder {
 	// device
 	uint8_t *d_raw = nullptr, *d_cs = nullptr;
 	uint32_t *d_seg = nullptr, *d_chunk_kept = nullptr, *d_chunk_rst = nullptr;
-	JhSubInfo *d_rec = nullptr;
+	JhSubInfo *d_rec = nullptr, *d_prec = nullptr;
+	unsigned long long *d_wg_key = nullptr;
 	uint32_t *d_meta = nullptr;
 	JhWgAgg *d_wg_agg = nullptr, *d_wg_base = nullptr;
 	JhSubStart *d_start = nullptr;
@@ -178,7 +179,8 @@ struct jpeg_hip_decoder {
 	{
 		hipFree(d_raw); hipFree(d_cs); hipFree(d_seg); hipFree(d_chunk_kept); hipFree(d_chunk_rst);
 		hipFree(d_start); hipFree(d_frames); hipFree(d_state); hipFree(d_luts);
-		hipFree(d_quant); hipFree(d_coefs); hipFree(d_rec); hipFree(d_meta); hipFree(d_wg_agg); hipFree(d_wg_base);
+		hipFree(d_quant); hipFree(d_coefs); hipFree(d_rec); hipFree(d_meta); hipFree(d_wg_agg); hipFree(d_wg_base); hipFree(d_prec); hipFree(d_wg_key);
+		d_prec = nullptr; d_wg_key = nullptr;
 		d_rec = nullptr; d_meta = nullptr; d_wg_agg = d_wg_base = nullptr;
 		d_raw = d_cs = nullptr; d_seg = d_chunk_kept = d_chunk_rst = nullptr;
 		d_start = nullptr; d_frames = nullptr; d_state = nullptr; d_luts = nullptr;
@@ -297,6 +299,9 @@ extern "C" int jpeg_hip_decoder_prepare(jpeg_hip_decoder *dec, int nframes,
 		fr.raw_begin = (uint32_t)(raw_off + h.ecs_offset);
 		fr.raw_end = (uint32_t)(raw_off + flen);
 		const size_t ecs = flen - h.ecs_offset;
+		if (ecs > 0x1ffffff0ull) {
+			return RET_FAILURE_OVERFLOW_ERROR;               // bit positions are 32-bit: < 512 MB of entropy-coded data per frame
+		}
 		fr.cs_off = (uint32_t)cs_off;
 		const size_t cs_cap = align_up(ecs + 32 + 1024, 64);     // staging reads some words past the end
 		fr.sub_off = (uint32_t)sub_off;
@@ -373,6 +378,8 @@ extern "C" int jpeg_hip_decoder_prepare(jpeg_hip_decoder *dec, int nframes,
 	HIPCHK(hipMalloc((void **)&dec->d_start, dec->sub_entries * sizeof(JhSubStart)));
 	HIPCHK(hipMalloc((void **)&dec->d_rec, dec->sub_entries * (JH_CHAIN_MAX + 1) * sizeof(JhSubInfo)));
 	HIPCHK(hipMalloc((void **)&dec->d_meta, dec->sub_entries * sizeof(uint32_t)));
+	HIPCHK(hipMalloc((void **)&dec->d_prec, dec->sub_entries * sizeof(JhSubInfo)));
+	HIPCHK(hipMalloc((void **)&dec->d_wg_key, (wg_off + 4) * sizeof(unsigned long long)));
 	HIPCHK(hipMalloc((void **)&dec->d_wg_agg, (wg_off + 4) * sizeof(JhWgAgg)));
 	HIPCHK(hipMalloc((void **)&dec->d_wg_base, (wg_off + 4) * sizeof(JhWgAgg)));
 	HIPCHK(hipMemset(dec->d_meta, 0, dec->sub_entries * sizeof(uint32_t)));
@@ -403,6 +410,8 @@ extern "C" int jpeg_hip_decoder_prepare(jpeg_hip_decoder *dec, int nframes,
 	w.chunk_rst = dec->d_chunk_rst;
 	w.rec = dec->d_rec;
 	w.meta = dec->d_meta;
+	w.prec = dec->d_prec;
+	w.wg_key = dec->d_wg_key;
 	w.wg_agg = dec->d_wg_agg;
 	w.wg_base = dec->d_wg_base;
 	w.start = dec->d_start;
@@ -541,7 +550,7 @@ extern "C" int jpeg_hip_decoder_get_stats(const jpeg_hip_decoder *dec, int frame
 		return RET_FAILURE_LOGIC_ERROR;
 	}
 	const JhDecState &s = dec->state[frame];
-	stats[0] = (s.status & JH_ST_SERIAL) ? 1u : 0u;
+	stats[0] = (s.status & JH_ST_SERIAL) ? (s.serial_cause ? s.serial_cause : 1u) : 0u;
 	stats[1] = s.nrepaired;
 	stats[2] = s.nblocks;
 	stats[3] = s.nseg;

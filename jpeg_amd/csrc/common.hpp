@@ -99,7 +99,7 @@ struct JhSubStart {                   // entry of a sub-sequence for the write p
 
 enum {                                // JhWgAgg.flags
 	JH_AGG_RESET = 1,                 // a restart boundary lies inside the emitted range
-	JH_AGG_BAD_NEXT = 2,              // the NEXT workgroup's default seed does not join the true parse in time
+	JH_AGG_GAP = 2,                   // the workgroup's path did not reach every sub-sequence of its range
 };
 #define JH_SEED_NONE 0xffffffffu
 
@@ -107,8 +107,7 @@ struct JhWgAgg {                      // one chains workgroup: totals of its emi
 	int32_t  nb;
 	uint32_t flags;
 	int32_t  dc[JH_MAX_COMP];
-	uint32_t next_seed;               // chain (local index in the NEXT workgroup) | first sub-sequence << 8 that
-	                                  // carries the true parse there, JH_SEED_NONE if unknown
+	uint32_t next_seed;               // unused (kept for the 32-byte layout)
 	uint32_t pad;
 };
 

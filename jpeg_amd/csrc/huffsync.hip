@@ -18,17 +18,20 @@
 //     The links form a forest; the true parse is a PATH in it.  The workgroup marks the path from
 //     its first chain (pointer doubling) and emits, for every sub-sequence on it from the
 //     JH_CHAIN_MAX-th on, the record decoded from the path's state, the exclusive prefix of blocks /
-//     DC sums inside the workgroup and the workgroup's totals.  The first JH_CHAIN_MAX sub-sequences
-//     are emitted by the PREVIOUS workgroup, whose path has long joined the true parse there; it also
-//     follows the next workgroup's first chain through its ghost zone and checks that both paths
-//     leave the zone in the same state -- which proves, workgroup by workgroup from the frame's first
-//     one (whose first chain IS the true parse), that every emitted record is on the true parse.
-//   k_huff_repair   a workgroup whose first chain did not join in time (a few in a thousand) re-emits from
-//     the chain its predecessor names as the carrier of the true parse.
-//   k_huff_finish   exclusive scan of the workgroup totals (one wave per frame).  Frames where the
-//     checks above failed twice in a row, or whose true parse contains garbage (corrupt streams: the
-//     reference skips to the end of the segment, decoder.c:376-381), are walked serially instead:
-//     slow, but right for ANY stream.
+//     DC sums inside the workgroup and the workgroup's totals -- plus the state it ASSUMED at its first
+//     emitted sub-sequence.  The first JH_CHAIN_MAX sub-sequences are emitted by the PREVIOUS workgroup,
+//     whose path has long joined the true parse there.
+//   k_huff_walk     (one wave per workgroup, a few rounds; normally returns at once)  If the state a
+//     workgroup assumed is not what its predecessor emitted, or its path had a hole (a chain cut
+//     before it merged: dense high-quality data synchronises slowly), the wave walks the true parse
+//     from the last trustworthy record -- following stored chains where one carries it, decoding by
+//     itself where none does -- until it falls in with the records already there.
+//   k_huff_finish   checks, workgroup by workgroup from the frame's first one (whose first chain IS the
+//     true parse), that every assumed entry state equals the predecessor's last record: that proves
+//     every emitted record is on the true parse.  Then the exclusive scan of the workgroup totals (one
+//     wave per frame).  Frames that fail the check, or whose walks gave up, are walked serially by one
+//     thread instead: slow, but right for ANY stream (corrupt ones included: the reference skips to
+//     the end of the segment at undecodable data, decoder.c:376-381).
 //
 // Restart markers need nothing extra: crossing a restart boundary puts every chain into the same
 // state, so all chains merge there at the latest.
@@ -42,6 +45,7 @@
 #define DIRN 4                          // distinct exit states remembered per sub-sequence
 #define NONE16 0xffffu
 #define META_RESTART 0x80000000u
+#define JH_WALK_ROUNDS 12                // a walk that changes a workgroup's last record sends its successor round again
 
 // parse state + restart segment as one comparable word (segment modulo 2^16: two chains at the same
 // bit position can only differ by the boundaries processed AT that position)
@@ -170,7 +174,9 @@ __device__ __forceinline__ Agg agg_of(const JhSubInfo &r)
 	return a;
 }
 
-// ---- path selection and emission (shared by k_huff_chains and k_huff_repair) ---------------------------
+// ---- path selection -------------------------------------------------------------------------------------
+
+#define REC_INVALID (1ull << 63)        // JhSubInfo.state: no record (the workgroup's path does not reach here)
 
 struct PathLds {
 	uint16_t succ[256];               // chain this chain merged into (local index), NONE16 = none
@@ -182,17 +188,17 @@ struct PathLds {
 	uint8_t cov[256];
 	JhSubInfo *trec;                  // records of the marked path, by local sub-sequence (256 entries of LDS)
 	Agg scratch[4];
-	int s_last, from_last;            // path chain that covers the last sub-sequence of the range, and since where
-	int broken;
-	int have2;
-	unsigned long long key2;
+	int gap;
 };
 
-// marks the chains on the path that starts with chain `seed`; pred[] = predecessor on the path
-__device__ __forceinline__ void mark_path(PathLds &L, int seed)
+// marks the chains on the path that starts with chain `seed`; pred[] = predecessor on the path.
+// A restart link that ends at or after local sub-sequence `trust` is not followed: from there on the
+// path claims to be the true parse, and a fresh guess is not.
+__device__ __forceinline__ void mark_path(PathLds &L, int seed, int trust)
 {
 	const int tid = threadIdx.x;
-	L.reach[0][tid] = L.succ[tid];
+	const bool cut = L.dflag[tid] && tid + (int)L.nst[tid] >= trust;
+	L.reach[0][tid] = cut ? (uint16_t)NONE16 : L.succ[tid];
 	L.mark[tid] = tid == seed ? 1 : 0;
 	L.pred[tid] = NONE16;
 	__syncthreads();
@@ -206,115 +212,38 @@ __device__ __forceinline__ void mark_path(PathLds &L, int seed)
 		__syncthreads();
 		rb ^= 1;
 	}
-	if (L.mark[tid] && L.succ[tid] != NONE16) {
+	if (L.mark[tid] && L.succ[tid] != NONE16 && !cut) {
 		L.pred[L.succ[tid]] = (uint16_t)tid;
 	}
 	__syncthreads();
 }
 
-struct EmitResult {
-	uint32_t flags_next;              // JH_AGG_BAD_NEXT or 0
-	uint32_t next_seed;
-	bool broken;
-};
-
-// Emits start[] for the local sub-sequences [lo, range_len) from the path that starts with chain
-// `seed` (trusted from local sub-sequence seed_from on), returns the totals through *total and what
-// the next workgroup needs to know.  rec = records of local chain 0; first = first workgroup of the frame.
-__device__ __forceinline__ EmitResult emit_path(PathLds &L, const JhSubInfo *rec, JhSubStart *start, int seed, int seed_from,
-                                                int lo, int range_len, bool first, bool need_next, Agg *total)
+// entry record of local sub-sequence jl of an emitted range from the exclusive prefix over the range
+__device__ __forceinline__ JhSubStart make_start(const Agg &excl, unsigned long long prev_state, uint32_t prev_seg)
 {
-	const int tid = threadIdx.x;
-	const int hi = range_len - 1;
-	if (tid == 0) {
-		L.s_last = -1;
-		L.from_last = 0;
-		L.broken = 0;
-		L.have2 = 0;
-	}
-	L.cov[tid] = 0;
-	mark_path(L, seed);
-	{
-		const bool onp = L.mark[tid] && tid < range_len;
-		if (onp) {
-			const int from = tid == seed ? seed_from : (int)L.pred[tid] + (int)L.nst[L.pred[tid]] + 1;
-			const int to = tid + (int)L.nst[tid];
-			for (int jl = max(from, 0); jl <= min(to, hi); ++jl) {
-				L.trec[jl] = rec[(size_t)tid * (KMAX + 1) + (jl - tid)];
-				L.cov[jl] = 1;
-			}
-			if (L.dflag[tid] && to >= lo - 1 && to < hi) {
-				L.broken = 1;              // the true parse itself ran into garbage: not for this scheme
-			}
-			if (from <= hi && hi <= to) {
-				L.s_last = tid;
-				L.from_last = from;
-			}
-		}
-	}
-	__syncthreads();
-	if (tid >= max(lo - 1, 0) && tid <= hi && !L.cov[tid]) {
-		L.broken = 1;                      // a chain on the path was cut before it merged
-	}
-	__syncthreads();
-	const bool broken = L.broken != 0;
-	const int s1 = L.s_last, from1 = L.from_last;
-
-	// prefix of blocks and DC sums over the emitted range, entry records
-	Agg v = agg_identity();
-	if (!broken && tid >= lo && tid <= hi) {
-		v = agg_of(L.trec[tid]);
-	}
-	Agg incl, excl;
-	block_seg_scan(v, L.scratch, incl, excl);
-	if (!broken && tid >= lo && tid <= hi) {
-		JhSubStart o;
-		if (tid == 0 && first) {
-			o.state = 0;                   // a DC code of block 0 starts at bit 0
-			o.seg = 0;
-		} else {
-			o.state = L.trec[tid - 1].state & STATE_SYNC_MASK;
-			o.seg = L.trec[tid - 1].seg;
-		}
-		o.state |= (unsigned long long)(excl.rs & 1) << 48;
-		o.blk = excl.nb;
+	JhSubStart o;
+	o.state = (prev_state & STATE_SYNC_MASK) | ((unsigned long long)(excl.rs & 1) << 48);
+	o.seg = prev_seg;
+	o.blk = excl.nb;
 #pragma unroll
-		for (int k = 0; k < JH_MAX_COMP; ++k) {
-			o.pred[k] = excl.dc[k];
-		}
-		start[tid] = o;
+	for (int k = 0; k < JH_MAX_COMP; ++k) {
+		o.pred[k] = excl.dc[k];
 	}
-	if (tid == 255) {
-		*total = incl;
-	}
+	return o;
+}
 
-	// what the next workgroup needs: does its first chain leave our ghost zone in the true state?
-	EmitResult res;
-	res.broken = broken;
-	res.flags_next = 0;
-	res.next_seed = JH_SEED_NONE;
-	if (need_next && !broken) {
-		const unsigned long long key1 = chain_key(L.trec[hi].state, L.trec[hi].seg);
-		__syncthreads();
-		mark_path(L, OWN);
-		if (L.mark[tid] && tid >= OWN && tid < range_len) {
-			const int from = tid == OWN ? OWN : (int)L.pred[tid] + (int)L.nst[L.pred[tid]] + 1;
-			const int to = tid + (int)L.nst[tid];
-			if (from <= hi && hi <= to) {
-				const JhSubInfo r = rec[(size_t)tid * (KMAX + 1) + (hi - tid)];
-				L.key2 = chain_key(r.state, r.seg);
-				L.have2 = 1;
-			}
-		}
-		__syncthreads();
-		const bool ok = L.have2 && L.key2 == key1;
-		res.flags_next = ok ? 0u : (uint32_t)JH_AGG_BAD_NEXT;
-		if (s1 >= OWN) {
-			res.next_seed = (uint32_t)(s1 - OWN) | ((uint32_t)(from1 - OWN) << 8);
-		}
+__device__ __forceinline__ void store_agg(JhWgAgg *dst, const Agg &t, uint32_t extra_flags)
+{
+	JhWgAgg o;
+	o.nb = t.nb;
+	o.flags = (t.rs ? (uint32_t)JH_AGG_RESET : 0u) | extra_flags;
+#pragma unroll
+	for (int k = 0; k < JH_MAX_COMP; ++k) {
+		o.dc[k] = t.dc[k];
 	}
-	__syncthreads();
-	return res;
+	o.next_seed = JH_SEED_NONE;
+	o.pad = 0;
+	*dst = o;
 }
 
 // =================================================================================== chains
@@ -465,7 +394,7 @@ __global__ __launch_bounds__(256) void k_huff_chains(const HuffArgs a)
 	}
 	__syncthreads();
 
-	// ---- links of the own chains (for the repair kernel and the serial walk) ---------------------
+	// ---- links of the own chains (for the walk kernels) ----------------------------------------------
 	const bool need_next = b + 1 < jh_num_chain_wgs(nsub);
 	if ((tid < OWN || !need_next) && tid < range_len) {
 		const uint32_t link = P.succ[tid] != NONE16 ? (uint32_t)(P.succ[tid] - tid) : 0u;
@@ -474,42 +403,171 @@ __global__ __launch_bounds__(256) void k_huff_chains(const HuffArgs a)
 
 	// ---- emit from the path of the first chain ---------------------------------------------------
 	static_assert(sizeof(dkey) >= 256 * sizeof(JhSubInfo), "the path records reuse the directory's LDS");
+	const int lo = b == 0 ? 0 : KMAX, hi = range_len - 1;
 	if (tid == 0) {
 		P.trec = reinterpret_cast<JhSubInfo *>(&dkey[0][0]);
+		P.gap = 0;
+	}
+	P.cov[tid] = 0;
+	mark_path(P, 0, lo - 1);
+	if (P.mark[tid] && tid < range_len) {
+		const int from = tid == 0 ? 0 : (int)P.pred[tid] + (int)P.nst[P.pred[tid]] + 1;
+		const int to = tid + (int)P.nst[tid];
+		for (int jl = from; jl <= min(to, hi); ++jl) {
+			P.trec[jl] = rec[(size_t)tid * (KMAX + 1) + (jl - tid)];
+			P.cov[jl] = 1;
+		}
 	}
 	__syncthreads();
-	const EmitResult er = emit_path(P, rec, w.start + fr.sub_off + j0, 0, 0, b == 0 ? 0 : KMAX, range_len, b == 0, need_next, &total);
+	const bool mine = tid >= lo && tid <= hi;
+	if (mine && !P.cov[tid]) {
+		P.gap = 1;                         // a chain on the path was cut, or the true parse ran into garbage
+	}
+	__syncthreads();
+	const bool gap = P.gap != 0;
+	JhSubInfo *prec = w.prec + fr.sub_off + j0;
+	if (mine) {
+		JhSubInfo r = P.trec[tid];
+		if (!P.cov[tid]) {
+			r.state = REC_INVALID;
+		}
+		prec[tid] = r;
+	}
+	Agg v = agg_identity();
+	if (mine && !gap) {
+		v = agg_of(P.trec[tid]);
+	}
+	Agg incl, excl;
+	block_seg_scan(v, P.scratch, incl, excl);
+	if (mine && !gap) {
+		const bool first = tid == 0;       // only in the frame's first workgroup: a DC code of block 0 starts at bit 0
+		w.start[fr.sub_off + j0 + tid] = make_start(excl, first ? 0ull : P.trec[tid - 1].state, first ? 0u : P.trec[tid - 1].seg);
+	}
+	if (tid == 255) {
+		store_agg(&w.wg_agg[fr.wg_off + b], incl, gap ? (uint32_t)JH_AGG_GAP : 0u);
+	}
 	if (tid == 0) {
-		JhWgAgg o;
-		o.nb = total.nb;
-		o.flags = (total.rs ? (uint32_t)JH_AGG_RESET : 0u) | er.flags_next;
-		if ((w.debug & 1) && need_next && (b & 1) == 0) {
-			o.flags |= (uint32_t)JH_AGG_BAD_NEXT;  // test hook: make the successor take the repair path
+		// the state this workgroup ASSUMED at its first emitted sub-sequence; the walk kernel compares it
+		// with what the predecessor says
+		unsigned long long key = REC_INVALID;
+		if (b > 0 && P.cov[lo - 1]) {
+			key = chain_key(P.trec[lo - 1].state, P.trec[lo - 1].seg);
 		}
-#pragma unroll
-		for (int k = 0; k < JH_MAX_COMP; ++k) {
-			o.dc[k] = total.dc[k];
+		if ((w.debug & 1) && (b & 1)) {
+			key = REC_INVALID;                 // test hook: make every other workgroup take the walk
 		}
-		o.next_seed = er.next_seed;
-		o.pad = 0;
-		w.wg_agg[fr.wg_off + b] = o;
-		if (er.broken || (w.debug & 2)) {
+		w.wg_key[fr.wg_off + b] = key;
+		if (w.debug & 2) {
 			atomicOr(&w.state[f].status, (uint32_t)JH_ST_SERIAL);
+			atomicOr(&w.state[f].serial_cause, 16u);
 		}
 	}
 }
 
-// =================================================================================== repair
+// =================================================================================== walk
 
-__global__ __launch_bounds__(256) void k_huff_repair(const HuffArgs a)
+struct WalkCtx {
+	const JhDecodeWork *w;
+	const JhDecFrame *fr;
+	const uint8_t *cs;
+	const uint32_t *seg_start;
+	const JhSubInfo *rec;                 // of the frame's chain 0
+	const uint32_t *meta;
+	uint32_t total_bits, nseg, nsub;
+	int B;
+};
+
+// Record of sub-sequence q decoded from the true entry state (T, Tseg).  r = stored chain known to
+// carry the true parse into q (0xffffffff: unknown), updated.  Executed by a whole wave: the lanes
+// check the candidate chains in parallel; lane 0 decodes by itself where no stored chain helps
+// (*selfdec counts those).  The result is returned in every lane.
+__device__ __forceinline__ JhSubInfo walk_step(const WalkCtx &c, unsigned long long T, uint32_t Tseg, uint32_t q, uint32_t &r,
+                                               const unsigned char *luts, const DecTables &tb, int *dcs, JhSubInfo *bcast,
+                                               int *selfdec)
 {
-	__shared__ PathLds P;
-	__shared__ Agg total;
-	__shared__ JhSubInfo trec_mem[256];
+	const int lane = threadIdx.x & 63;
+	JhSubInfo R;
+	if ((uint32_t)(T & 0xffffffffu) >= c.total_bits) {
+		// the parse has ended (end of data, or garbage with no restart segment left)
+		R.state = T & STATE_SYNC_MASK;
+		R.seg = Tseg;
+		R.nb = 0;
+#pragma unroll
+		for (int k = 0; k < JH_MAX_COMP; ++k) {
+			R.dc[k] = 0;
+		}
+		r = 0xffffffffu;
+		return R;
+	}
+	const unsigned long long keyT = chain_key(T, Tseg);
+	if (r == 0xffffffffu) {
+		// a stored chain that ENTERS q in the true state?  chain q itself (lane 0) or an older one (lane d)
+		bool hit = false;
+		if (lane <= KMAX && (uint32_t)lane <= q) {
+			const uint32_t ch = q - (uint32_t)lane;
+			const uint32_t steps = c.meta[ch] & 0xffu;
+			if ((uint32_t)lane <= steps) {
+				if (lane == 0) {
+					const uint32_t p0 = q * JH_SUBSEQ_BITS;
+					const uint32_t s0 = c.nseg > 1 ? find_segment(c.seg_start, c.nseg, p0 >> 3) : 0u;
+					hit = chain_key((unsigned long long)p0, s0) == keyT;
+				} else {
+					const JhSubInfo x = c.rec[(size_t)ch * (KMAX + 1) + (lane - 1)];
+					hit = chain_key(x.state, x.seg) == keyT;
+				}
+			}
+		}
+		const unsigned long long m = __ballot(hit);
+		if (m) {
+			r = q - (uint32_t)(__ffsll((long long)m) - 1);
+		}
+	}
+	if (r != 0xffffffffu) {
+		const uint32_t m = c.meta[r];
+		const uint32_t steps = m & 0xffu, link = (m >> 8) & 0xffu, d = q - r;
+		R = c.rec[(size_t)r * (KMAX + 1) + d];
+		if (d == steps) {
+			// the chain ends here: follow a true merge, never a restart link
+			r = (link != 0 && !(m & META_RESTART)) ? r + link : 0xffffffffu;
+		}
+		return R;
+	}
+	if (lane == 0) {
+		DecState st;
+		state_from(st, T, Tseg);
+		if (st.c >= c.B || st.z > 63 || st.seg >= c.nseg) {
+			st.pos = c.total_bits;             // cannot happen for states produced by decode_span
+		}
+		decode_span<false>(st, (q + 1) * JH_SUBSEQ_BITS, RegStream{c.cs}, c.total_bits, c.seg_start, c.nseg, luts, tb, c.B, dcs, 64,
+		                   nullptr, 0, 0);
+		store_info(bcast, st);
+		*selfdec += 1;
+	}
+	__builtin_amdgcn_wave_barrier();
+	__threadfence_block();
+	R = *bcast;
+	return R;
+}
+
+#define WALK_SELF_LIMIT 96              // sub-sequences one wave may decode by itself per round before giving up
+
+// One wave per chains workgroup; does nothing unless the workgroup's assumed entry state differs from
+// what its predecessor emitted, or its own path had a hole.  Then it walks the true parse from the
+// last trustworthy record -- following stored chains where one carries it, decoding where none does --
+// until it falls in with the records already emitted, and redoes the workgroup's prefix sums.
+__global__ __launch_bounds__(64) void k_huff_walk(const HuffArgs a)
+{
+	extern __shared__ __align__(16) unsigned char smem[];
+	unsigned char *luts = smem;
+	__shared__ DecTables tb;
+	__shared__ int dcs[JH_MAX_COMP][64];
+	__shared__ JhSubInfo prl[256];
+	__shared__ JhSubInfo bcast;
+	__shared__ int selfdec;
 
 	const JhDecodeWork &w = a.w;
 	const int f = blockIdx.y;
-	const uint32_t b = blockIdx.x + 1;
+	const uint32_t b = blockIdx.x;
 	const JhDecFrame fr = w.frames[f];
 	const JhDecState fs = w.state[f];
 	const uint32_t total_bits = fs.cs_len * 8u;
@@ -517,65 +575,121 @@ __global__ __launch_bounds__(256) void k_huff_repair(const HuffArgs a)
 	if (nsub == 0 || b >= jh_num_chain_wgs(nsub) || (fs.status & JH_ST_SERIAL)) {
 		return;
 	}
-	const JhWgAgg prev = w.wg_agg[fr.wg_off + b - 1];
-	if (!(prev.flags & JH_AGG_BAD_NEXT)) {
-		return;                            // the common case: the first chain joined the true parse in time
+	const int lane = threadIdx.x;
+	const uint32_t j0 = b * (uint32_t)OWN;
+	const int range_len = (int)min(256u, nsub - j0);
+	const int lo = b == 0 ? 0 : KMAX, hi = range_len - 1;
+	JhSubInfo *prec = w.prec + fr.sub_off + j0;
+	JhWgAgg *agg = &w.wg_agg[fr.wg_off + b];
+	const bool gap = (agg->flags & JH_AGG_GAP) != 0;
+	JhSubInfo pe;
+	pe.state = 0;
+	pe.seg = 0;
+	bool mismatch = false;
+	if (b > 0) {
+		pe = prec[lo - 1];                    // the predecessor's last record = the state this range starts in
+		if (pe.state & REC_INVALID) {
+			return;                           // the predecessor still has a hole: a later round
+		}
+		mismatch = chain_key(pe.state, pe.seg) != w.wg_key[fr.wg_off + b];
 	}
-	const int tid = threadIdx.x;
-	// the predecessor's own path must be beyond doubt, and it must know the carrier
-	const bool prev_bad = b >= 2 && (w.wg_agg[fr.wg_off + b - 2].flags & JH_AGG_BAD_NEXT);
-	if (prev_bad || prev.next_seed == JH_SEED_NONE) {
-		if (tid == 0) {
+	if (!mismatch && !gap) {
+		return;
+	}
+	load_tables(w, fr, luts, &tb, a.g, 64);
+	for (int jl = lo + lane; jl <= hi; jl += 64) {
+		prl[jl] = prec[jl];
+	}
+	if (lane == 0) {
+		selfdec = 0;
+	}
+	__syncthreads();
+
+	WalkCtx c;
+	c.w = &w;
+	c.fr = &fr;
+	c.cs = w.cs + fr.cs_off;
+	c.seg_start = w.seg_start + fr.seg_off;
+	c.rec = w.rec + (size_t)fr.sub_off * (KMAX + 1);
+	c.meta = w.meta + fr.sub_off;
+	c.total_bits = total_bits;
+	c.nseg = min(fs.nseg, fr.seg_cap - 1);
+	c.nsub = nsub;
+	c.B = a.g.B;
+
+	unsigned long long T = pe.state & STATE_SYNC_MASK;
+	uint32_t Tseg = pe.seg;
+	bool in_sync = !mismatch;
+	uint32_t r = 0xffffffffu;
+	const unsigned long long old_exit = prl[hi].state & REC_INVALID ? REC_INVALID : chain_key(prl[hi].state, prl[hi].seg);
+	bool gave_up = false;
+	for (int q = lo; q <= hi; ++q) {
+		const JhSubInfo old = prl[q];
+		const bool oldvalid = !(old.state & REC_INVALID);
+		if (in_sync && oldvalid) {
+			T = old.state & STATE_SYNC_MASK;
+			Tseg = old.seg;
+			r = 0xffffffffu;
+			continue;
+		}
+		if (selfdec > WALK_SELF_LIMIT) {
+			gave_up = true;
+			break;
+		}
+		const JhSubInfo R = walk_step(c, T, Tseg, j0 + (uint32_t)q, r, luts, tb, &dcs[0][lane], &bcast, &selfdec);
+		in_sync = oldvalid && chain_key(old.state, old.seg) == chain_key(R.state, R.seg);
+		__builtin_amdgcn_wave_barrier();
+		if (lane == 0) {
+			prl[q] = R;
+		}
+		__builtin_amdgcn_wave_barrier();
+		__threadfence_block();
+		T = R.state & STATE_SYNC_MASK;
+		Tseg = R.seg;
+	}
+	if (gave_up) {
+		if (lane == 0) {
 			atomicOr(&w.state[f].status, (uint32_t)JH_ST_SERIAL);
+			atomicOr(&w.state[f].serial_cause, 4u);
 		}
 		return;
 	}
-	const uint32_t j0 = b * (uint32_t)OWN;
-	const int range_len = (int)min(256u, nsub - j0);
-	const uint32_t *meta = w.meta + fr.sub_off + j0;
-	JhSubInfo *rec = w.rec + (size_t)(fr.sub_off + j0) * (KMAX + 1);
-	{
-		uint16_t su = NONE16;
-		uint8_t ns = 0, df = 0;
-		if (tid < range_len) {
-			const uint32_t m = meta[tid];
-			int steps = (int)(m & 0xffu);
-			const int link = (int)((m >> 8) & 0xffu);
-			if (tid + steps > range_len - 1 || (link != 0 && tid + link > range_len - 1)) {
-				steps = min(steps, range_len - 1 - tid);   // the range ends before the chain does
-			} else if (link != 0) {
-				su = (uint16_t)(tid + link);
-				df = (m & META_RESTART) ? 1 : 0;
-			}
-			ns = (uint8_t)steps;
-		}
-		P.succ[tid] = su;
-		P.nst[tid] = ns;
-		P.dflag[tid] = df;
-		if (tid == 0) {
-			P.trec = trec_mem;
-		}
-	}
 	__syncthreads();
-	const int seed = (int)(prev.next_seed & 0xffu), seed_from = (int)(prev.next_seed >> 8);
-	const bool need_next = b + 1 < jh_num_chain_wgs(nsub);
-	const EmitResult er = emit_path(P, rec, w.start + fr.sub_off + j0, seed, seed_from, KMAX, range_len, false, need_next, &total);
-	if (tid == 0) {
-		JhWgAgg *o = &w.wg_agg[fr.wg_off + b];
-		// BAD_NEXT / next_seed stay as they are (the successor may be reading them right now); if the
-		// repaired path disagrees with them the frame is walked serially
-		const bool differs = need_next && ((o->flags & JH_AGG_BAD_NEXT) != er.flags_next || o->next_seed != er.next_seed);
-		if (er.broken || differs) {
-			atomicOr(&w.state[f].status, (uint32_t)JH_ST_SERIAL);
-		} else {
-			atomicAdd(&w.state[f].nrepaired, 1u);
-			o->nb = total.nb;
-#pragma unroll
-			for (int k = 0; k < JH_MAX_COMP; ++k) {
-				o->dc[k] = total.dc[k];
-			}
-			o->flags = (o->flags & (uint32_t)JH_AGG_BAD_NEXT) | (total.rs ? (uint32_t)JH_AGG_RESET : 0u);
+	// records back, prefix sums and entry records of the whole range again
+	Agg carry = agg_identity();
+	for (int t0 = lo; t0 <= hi; t0 += 64) {
+		const int jl = t0 + lane;
+		const bool have = jl <= hi;
+		Agg v = agg_identity();
+		if (have) {
+			prec[jl] = prl[jl];
+			v = agg_of(prl[jl]);
 		}
+		Agg incl, excl;
+		wave_seg_scan(v, incl, excl);
+		if (have) {
+			const Agg e = agg_combine(carry, excl);
+			const bool first = b == 0 && jl == 0;
+			const unsigned long long ps = first ? 0ull : (jl == lo ? pe.state : prl[jl - 1].state);
+			const uint32_t pg = first ? 0u : (jl == lo ? pe.seg : prl[jl - 1].seg);
+			w.start[fr.sub_off + j0 + jl] = make_start(e, ps, pg);
+		}
+		Agg last;
+		last.nb = __shfl(incl.nb, 63, 64);
+		last.rs = __shfl(incl.rs, 63, 64);
+#pragma unroll
+		for (int k = 0; k < JH_MAX_COMP; ++k) {
+			last.dc[k] = __shfl(incl.dc[k], 63, 64);
+		}
+		carry = agg_combine(carry, last);
+	}
+	if (lane == 0) {
+		store_agg(agg, carry, 0u);
+		if (b > 0) {
+			w.wg_key[fr.wg_off + b] = chain_key(pe.state, pe.seg);
+		}
+		atomicAdd(&w.state[f].nrepaired, 1u);
+		(void)old_exit;
 	}
 }
 
@@ -709,6 +823,29 @@ __global__ __launch_bounds__(64) void k_huff_finish(const HuffArgs a)
 		}
 		return;
 	}
+	// every workgroup's assumed entry state must be its predecessor's last record, no holes left
+	bool bad = false;
+	for (uint32_t b0 = 0; b0 < nwg; b0 += 64) {
+		const uint32_t b = b0 + threadIdx.x;
+		if (b < nwg) {
+			bad |= (w.wg_agg[fr.wg_off + b].flags & JH_AGG_GAP) != 0;
+			if (b > 0) {
+				const JhSubInfo pe = w.prec[fr.sub_off + b * (uint32_t)OWN + KMAX - 1];
+				bad |= (pe.state & REC_INVALID) != 0 || chain_key(pe.state, pe.seg) != w.wg_key[fr.wg_off + b];
+			}
+		}
+	}
+	if (__any(bad)) {
+		if (threadIdx.x == 0) {
+			fs.status |= JH_ST_SERIAL;
+			fs.serial_cause |= 2u;
+		}
+		load_tables(w, fr, luts, &tb, a.g, 64);
+		if (threadIdx.x == 0) {
+			serial_walk(a, fr, fs, nsub, nwg, luts, tb, &dcs[0][0]);
+		}
+		return;
+	}
 	Agg carry = agg_identity();
 	for (uint32_t b0 = 0; b0 < nwg; b0 += 64) {
 		const uint32_t b = b0 + threadIdx.x;
@@ -772,9 +909,10 @@ int jh_launch_huff_sync(const JhDecodeWork &w, const JhGeom &g, hipStream_t s, c
 	JH_T_BEGIN(th, "k_huff_chains", s);
 	hipLaunchKernelGGL(k_huff_chains, dim3(nwg, w.nframes), dim3(256), lds_chains, s, a);
 	JH_T_END(th, s);
-	JH_T_BEGIN(th, "k_huff_repair", s);
-	if (nwg > 1) {
-		hipLaunchKernelGGL(k_huff_repair, dim3(nwg - 1, w.nframes), dim3(256), 0, s, a);
+	JH_T_BEGIN(th, "k_huff_walk", s);
+	for (int round = 0; round < JH_WALK_ROUNDS; ++round) {
+		a.round = round;
+		hipLaunchKernelGGL(k_huff_walk, dim3(nwg, w.nframes), dim3(64), lds, s, a);
 	}
 	JH_T_END(th, s);
 	JH_T_BEGIN(th, "k_huff_finish", s);

@@ -43,7 +43,9 @@ struct JhDecState {               // written by the device
 	uint32_t nseg;                // restart segments
 	uint32_t status;
 	uint32_t nblocks;             // blocks decoded (for diagnostics)
-	uint32_t nrepaired;           // chains workgroups re-emitted by k_huff_repair (for diagnostics)
+	uint32_t nrepaired;           // chains workgroups redone by k_huff_walk (for diagnostics)
+	uint32_t serial_cause;        // why the serial walk was asked for: 2 entry states still
+	                              // inconsistent after the walk rounds, 4 a walk had to decode too much by itself, 16 test hook
 	uint32_t term_marker;         // second byte of the marker at term_pos (0xd9 = EOI)
 };
 
@@ -54,7 +56,9 @@ struct JhDecodeWork {             // device pointers of one decoder batch
 	uint32_t *chunk_kept, *chunk_rst;
 	JhSubInfo *rec;               // [sub-sequence t][step d <= JH_CHAIN_MAX]: chain t after sub-sequence t + d
 	uint32_t *meta;               // per chain: steps walked | (link distance << 8) | restarted-after-garbage << 31
-	JhWgAgg *wg_agg;              // per chains workgroup: totals of its emitted range, flags, seed of the next one
+	JhSubInfo *prec;              // per sub-sequence: its record on the emitting workgroup's path (bit 63 of state: none)
+	unsigned long long *wg_key;   // per chains workgroup: the entry state its emitted records assume
+	JhWgAgg *wg_agg;              // per chains workgroup: totals of its emitted range, flags
 	JhWgAgg *wg_base;             // per chains workgroup: exclusive prefix of the totals
 	JhSubStart *start;            // entry records for the write pass (relative to the workgroup's base)
 	const JhDecFrame *frames;

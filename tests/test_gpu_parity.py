@@ -220,8 +220,8 @@ def test_sync_paths_agree_on_a_multi_workgroup_stream(hip, oracle):
                 assert np.array_equal(px, opx)
             d.close()
         assert seen[0][0] == 0                           # fast path: no serial walk on a sane stream
-        assert seen[1][1] > 0 or seen[1][0] == 1         # forced: workgroups really were repaired
-        assert seen[2][0] == 1                           # forced: the serial walk really ran
+        assert seen[1][1] > 0 or seen[1][0] != 0         # forced: workgroups really were repaired
+        assert seen[2][0] != 0                           # forced: the serial walk really ran
         assert seen[0][2] == seen[1][2] == seen[2][2]    # same number of blocks decoded
 
 
