@@ -338,14 +338,14 @@ def decode(jpgs, device=0):
         d.close()
 
 
-def encode(images, P=8, H=2, V=1, q=75, optimize=1, device=0):
+def encode(images, P=8, H=2, V=1, q=75, optimize=1, device=0, restart_interval=0):
     """Convenience: list of same-shaped images -> (list of JPEG bytes, list of RET codes)."""
     a0 = np.asarray(images[0])
     Y, X = a0.shape[:2]
     Nf = 1 if a0.ndim == 2 else a0.shape[2]
     e = Encoder(device)
     try:
-        e.configure(len(images), X, Y, Nf, P, H, V, q, optimize)
+        e.configure(len(images), X, Y, Nf, P, H, V, q, optimize, restart_interval)
         e.run(e.upload(images))
         st, ln = e.sync()
         return [e.jpeg(f, ln[f]) if st[f] == 0 else None for f in range(len(images))], st

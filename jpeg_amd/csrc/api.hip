@@ -588,6 +588,7 @@ struct jpeg_hip_encoder {
 	int16_t *d_coefs = nullptr;
 	JhHuffEnc *d_codes = nullptr;
 	uint32_t *d_hist = nullptr, *d_wg_bits = nullptr, *d_us = nullptr, *d_chunk_ff = nullptr, *d_hdr_len = nullptr;
+	uint32_t *d_ivl_raw = nullptr, *d_ivl_padsum = nullptr, *d_ivl_eb = nullptr;
 	uint16_t *d_bitlen = nullptr;
 	uint8_t *d_out = nullptr;
 	JhEncState *d_state = nullptr;
@@ -600,6 +601,8 @@ struct jpeg_hip_encoder {
 	{
 		hipFree(d_quant); hipFree(d_coefs); hipFree(d_codes); hipFree(d_hist); hipFree(d_wg_bits);
 		hipFree(d_us); hipFree(d_chunk_ff); hipFree(d_hdr_len); hipFree(d_bitlen); hipFree(d_out); hipFree(d_state);
+		hipFree(d_ivl_raw); hipFree(d_ivl_padsum); hipFree(d_ivl_eb);
+		d_ivl_raw = d_ivl_padsum = d_ivl_eb = nullptr;
 		d_quant = nullptr; d_coefs = nullptr; d_codes = nullptr; d_hist = d_wg_bits = d_us = d_chunk_ff = d_hdr_len = nullptr;
 		d_bitlen = nullptr; d_out = nullptr; d_state = nullptr;
 	}
@@ -675,8 +678,8 @@ extern "C" int jpeg_hip_encoder_configure(jpeg_hip_encoder *enc, int nframes, in
 	if (Nf == 3 && (params->H < 1 || params->H > 2 || params->V < 1 || params->V > 2)) {
 		return RET_FAILURE_FILE_UNSUPPORTED;               // assert in the reference (encoder.c:123-124)
 	}
-	if (params->restart_interval != 0) {
-		return RET_FAILURE_FILE_UNSUPPORTED;               // restart-marker ENCODE: next
+	if (params->restart_interval < 0 || params->restart_interval > 65535) {
+		return RET_FAILURE_FILE_UNSUPPORTED;               // DRI holds 16 bits (extension: the reference writes none)
 	}
 	enc->prm = *params;
 	enc->nframes = nframes;
@@ -718,6 +721,7 @@ extern "C" int jpeg_hip_encoder_configure(jpeg_hip_encoder *enc, int nframes, in
 	w.nchunk = (int)(w.us_stride / 4096);
 	w.out_stride = align_up(4096 + w.us_stride + w.us_stride / 8, 4096);
 	w.restart_interval = params->restart_interval;
+	w.nivl = w.restart_interval > 0 ? (g.nmcu + w.restart_interval - 1) / w.restart_interval : 0;
 
 	HIPCHK(hipMalloc((void **)&enc->d_quant, nframes * sizeof(JhQuant)));
 	HIPCHK(hipMalloc((void **)&enc->d_coefs, (size_t)nframes * g.nblk * 64 * sizeof(int16_t)));
@@ -730,6 +734,14 @@ extern "C" int jpeg_hip_encoder_configure(jpeg_hip_encoder *enc, int nframes, in
 	HIPCHK(hipMalloc((void **)&enc->d_bitlen, (size_t)nframes * g.nblk * sizeof(uint16_t)));
 	HIPCHK(hipMalloc((void **)&enc->d_out, (size_t)nframes * w.out_stride));
 	HIPCHK(hipMalloc((void **)&enc->d_state, nframes * sizeof(JhEncState)));
+	if (w.nivl > 0) {
+		HIPCHK(hipMalloc((void **)&enc->d_ivl_raw, (size_t)nframes * w.nivl * sizeof(uint32_t)));
+		HIPCHK(hipMalloc((void **)&enc->d_ivl_padsum, (size_t)nframes * (w.nivl + 1) * sizeof(uint32_t)));
+		HIPCHK(hipMalloc((void **)&enc->d_ivl_eb, (size_t)nframes * w.nivl * sizeof(uint32_t)));
+	}
+	w.ivl_raw = enc->d_ivl_raw;
+	w.ivl_padsum = enc->d_ivl_padsum;
+	w.ivl_eb = enc->d_ivl_eb;
 	w.coefs = enc->d_coefs;
 	w.codes = enc->d_codes;
 	w.hist = enc->d_hist;

@@ -20,6 +20,13 @@
 //
 // The whole image is ONE entropy-coded segment, as in the reference (no restart markers: quirk Q2).
 // Integer work: the produced bytes are identical to write_ecs()'s.
+//
+// EXTENSION (restart_interval > 0): DRI + RSTn.  Every interval starts on a byte
+// boundary, so its padding depends only on its own bit count: k_enc_ivl_ends / k_enc_ivl_scan turn the
+// per-block bit counts into per-interval paddings and their prefix sums; k_enc_pack shifts every block by
+// the padding before its interval and appends the 1-bits to the interval's last block; the stuffing
+// kernels insert FF D0+(k mod 8) at the interval ends (markers are not stuffed).  Judge: the reference
+// decoder decodes these streams to the same samples (tests).
 #include <hip/hip_runtime.h>
 #include "common.hpp"
 #include "kernels.hpp"
@@ -284,12 +291,97 @@ __global__ __launch_bounds__(256) void k_enc_wg_scan(const EncArgs a)
 		wg[w.nwg] = T;
 		st.total_bits = T;
 		st.us_bytes = (T + 7) >> 3;
-		if (!(st.status & JH_EST_OVERFLOW)) {
+		if (!(st.status & JH_EST_OVERFLOW) && w.restart_interval == 0) {
 			// flush_bits (io.c:65-87): pad the last byte with 1s
 			const unsigned pad = (8 - (T & 7)) & 7;
 			const unsigned mask = pad ? (((1u << pad) - 1u) << (32 - (T & 31) - pad)) : 0u;
 			us[T >> 5] = __builtin_bswap32(mask);
 		}
+	}
+}
+
+// ---------------------------------------------------------------------------------------- restart intervals
+
+__device__ __forceinline__ int interval_of_block(int blk, int B, int ri)
+{
+	return (blk / B) / ri;
+}
+
+// one thread per interval: entropy-coded bits before its end (no padding yet)
+__global__ __launch_bounds__(256) void k_enc_ivl_ends(const EncArgs a)
+{
+	const JhEncodeWork &w = a.w;
+	const JhGeom &g = a.g;
+	const int f = blockIdx.y;
+	const int k = blockIdx.x * 256 + threadIdx.x;
+	if (k >= w.nivl) {
+		return;
+	}
+	const int end_mcu = min((k + 1) * w.restart_interval, g.nmcu);
+	const int e = end_mcu * g.B;                                   // first block AFTER the interval
+	const uint32_t *wg = w.wg_bits + (size_t)f * (w.nwg + 1);
+	const uint16_t *bl = w.bitlen + (size_t)f * g.nblk;
+	uint32_t bits = wg[e >> 8];
+	for (int i = e & ~255; i < e; ++i) {
+		bits += bl[i];
+	}
+	w.ivl_raw[(size_t)f * w.nivl + k] = bits;
+}
+
+// one workgroup per frame: paddings, their exclusive prefix, interval ends in bytes, totals
+__global__ __launch_bounds__(256) void k_enc_ivl_scan(const EncArgs a)
+{
+	__shared__ unsigned scratch[4];
+	const JhEncodeWork &w = a.w;
+	const JhGeom &g = a.g;
+	const int f = blockIdx.x;
+	JhEncState &st = w.state[f];
+	if (st.status & JH_EST_OVERFLOW) {
+		return;
+	}
+	const uint32_t *raw = w.ivl_raw + (size_t)f * w.nivl;
+	uint32_t *padsum = w.ivl_padsum + (size_t)f * (w.nivl + 1);
+	uint32_t *eb = w.ivl_eb + (size_t)f * w.nivl;
+	const uint32_t *wg = w.wg_bits + (size_t)f * (w.nwg + 1);
+	uint32_t *us = w.us + (size_t)f * (w.us_stride / 4);
+	unsigned carry = 0;
+	for (int k0 = 0; k0 < w.nivl; k0 += 256) {
+		const int k = k0 + threadIdx.x;
+		unsigned pad = 0, end = 0;
+		if (k < w.nivl) {
+			end = raw[k];
+			const unsigned begin = k ? raw[k - 1] : 0u;
+			pad = (8u - ((end - begin) & 7u)) & 7u;               // flush_bits (io.c:65-87) per interval
+		}
+		unsigned total;
+		const unsigned before = carry + block_excl(pad, scratch, &total);
+		if (k < w.nivl) {
+			padsum[k] = before;
+			eb[k] = (end + before + pad) >> 3;
+		}
+		carry += total;
+	}
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		padsum[w.nivl] = carry;
+		const unsigned T = wg[w.nwg] + carry;
+		st.total_bits = T;
+		st.us_bytes = T >> 3;
+		if ((unsigned long long)T + 64 > (unsigned long long)(w.us_stride - 8) * 8) {
+			st.status |= JH_EST_OVERFLOW;
+		} else {
+			us[T >> 5] = 0;                                        // the last, partial word is merged by OR
+		}
+	}
+	__syncthreads();
+	if (st.status & JH_EST_OVERFLOW) {
+		return;
+	}
+	// words shared by two workgroups are merged by OR: clear them first
+	for (int x = threadIdx.x; x < w.nwg; x += 256) {
+		const int blk = x * 256;
+		const unsigned r0 = wg[x] + padsum[interval_of_block(min(blk, g.nblk - 1), g.B, w.restart_interval)];
+		us[r0 >> 5] = 0;
 	}
 }
 
@@ -310,11 +402,29 @@ __global__ __launch_bounds__(256) void k_enc_pack(const EncArgs a)
 		(&codes[0][0])[i] = w.codes[(size_t)f * 4 + (i >> 8)].code[i & 255];
 	}
 	const uint32_t *wg = w.wg_bits + (size_t)f * (w.nwg + 1);
-	const uint32_t r0 = wg[blockIdx.x], r1 = wg[blockIdx.x + 1];   // this workgroup's bit range
+	uint32_t r0 = wg[blockIdx.x], r1 = wg[blockIdx.x + 1];         // this workgroup's bit range
 	const int blk = blockIdx.x * 256 + threadIdx.x;
 	const int16_t *fc = w.coefs + (size_t)f * g.nblk * 64;
 	const bool have = blk < g.nblk;
-	const unsigned mylen = have ? w.bitlen[(size_t)f * g.nblk + blk] : 0u;
+	unsigned mylen = have ? w.bitlen[(size_t)f * g.nblk + blk] : 0u;
+	const int ri = w.restart_interval;
+	unsigned mypad = 0;
+	if (ri > 0) {
+		// restart intervals (extension): everything moves by the padding before its interval, and the last
+		// block of an interval carries the interval's padding
+		const uint32_t *padsum = w.ivl_padsum + (size_t)f * (w.nivl + 1);
+		const int first = blockIdx.x * 256, next = first + 256;
+		r0 += padsum[interval_of_block(first, g.B, ri)];
+		r1 += next < g.nblk ? padsum[interval_of_block(next, g.B, ri)] : padsum[w.nivl];
+		if (have) {
+			const int mcu = blk / g.B;
+			if (blk - mcu * g.B == g.B - 1 && ((mcu + 1) % ri == 0 || mcu + 1 == g.nmcu)) {
+				const int k = mcu / ri;
+				mypad = padsum[k + 1] - padsum[k];
+				mylen += mypad;
+			}
+		}
+	}
 	unsigned total;
 	const uint32_t start = r0 + block_excl(mylen, scratch, &total);   // barrier inside: codes[] visible after
 	if (r1 == r0) {
@@ -367,6 +477,9 @@ __global__ __launch_bounds__(256) void k_enc_pack(const EncArgs a)
 				const uint32_t e = ca[rs];
 				put(((e >> 8) << cat) | extra, (int)(e & 0xffu) + cat);
 			});
+			if (mypad) {
+				put((1u << mypad) - 1u, (int)mypad);           // flush_bits at the end of a restart interval
+			}
 			if (nacc > 0) {
 				const uint32_t rel = widx - wbase;
 				if (rel < WIN_WORDS) {
@@ -393,6 +506,30 @@ __global__ __launch_bounds__(256) void k_enc_pack(const EncArgs a)
 
 // ---------------------------------------------------------------------------------------- byte stuffing
 
+// RSTn markers go in FRONT of the bytes at eb[0 .. n): how many of them fall into [lo, hi); *first = index
+// of the first one at or after lo
+__device__ __forceinline__ unsigned markers_in(const uint32_t *eb, int n, uint32_t lo, uint32_t hi, int *first)
+{
+	int a = 0, b = n;                                             // lower bound of lo
+	while (a < b) {
+		const int m = (a + b) >> 1;
+		if (eb[m] < lo) {
+			a = m + 1;
+		} else {
+			b = m;
+		}
+	}
+	if (first) {
+		*first = a;
+	}
+	unsigned c = 0;
+	while (a < n && eb[a] < hi) {
+		++a;
+		++c;
+	}
+	return c;
+}
+
 __global__ __launch_bounds__(256) void k_enc_ffcount(const EncArgs a)
 {
 	__shared__ unsigned scratch[4];
@@ -412,6 +549,9 @@ __global__ __launch_bounds__(256) void k_enc_ffcount(const EncArgs a)
 		for (int i = 0; i < 16; ++i) {
 			const unsigned byte = (ws[i >> 2] >> (8 * (i & 3))) & 0xffu;
 			cnt += (base + i < nbytes && byte == 0xffu) ? 1u : 0u;
+		}
+		if (w.restart_interval > 0) {
+			cnt += 2u * markers_in(w.ivl_eb + (size_t)f * w.nivl, w.nivl - 1, base, base + 16, nullptr);
 		}
 	}
 	const unsigned total = block_sum(cnt, scratch);
@@ -469,6 +609,9 @@ __global__ __launch_bounds__(256) void k_enc_stuff(const EncArgs a)
 	const uint32_t base = blockIdx.x * FF_CHUNK + threadIdx.x * 16;
 	unsigned bytes[16];
 	unsigned cnt = 0;
+	const uint32_t *eb = w.ivl_eb + (size_t)f * w.nivl;
+	const int nmark = w.restart_interval > 0 ? w.nivl - 1 : 0;
+	int kb = 0;                                                   // next restart marker
 	if (base < nbytes) {
 		const uint4 v = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(w.us) + (size_t)f * w.us_stride + base);
 		const unsigned ws[4] = {v.x, v.y, v.z, v.w};
@@ -476,6 +619,9 @@ __global__ __launch_bounds__(256) void k_enc_stuff(const EncArgs a)
 		for (int i = 0; i < 16; ++i) {
 			bytes[i] = (ws[i >> 2] >> (8 * (i & 3))) & 0xffu;
 			cnt += (base + i < nbytes && bytes[i] == 0xffu) ? 1u : 0u;
+		}
+		if (nmark > 0) {
+			cnt += 2u * markers_in(eb, nmark, base, base + 16, &kb);
 		}
 	}
 	unsigned total;
@@ -488,6 +634,11 @@ __global__ __launch_bounds__(256) void k_enc_stuff(const EncArgs a)
 #pragma unroll
 	for (int i = 0; i < 16; ++i) {
 		if (base + i < nbytes) {
+			if (kb < nmark && eb[kb] == base + i) {
+				out[o++] = 0xff;                                   // RSTn in front of the interval's first byte
+				out[o++] = (uint8_t)(0xd0 + (kb & 7));
+				++kb;
+			}
 			out[o++] = (uint8_t)bytes[i];
 			if (bytes[i] == 0xffu) {
 				out[o++] = 0x00;
@@ -507,6 +658,12 @@ int jh_launch_enc_entropy(const JhEncodeWork &w, const JhGeom &g, hipStream_t s,
 	JH_T_BEGIN(th, "k_enc_wg_scan", s);
 	hipLaunchKernelGGL(k_enc_wg_scan, dim3(w.nframes), dim3(256), 0, s, a);
 	JH_T_END(th, s);
+	if (w.restart_interval > 0) {
+		JH_T_BEGIN(th, "k_enc_ivl", s);
+		hipLaunchKernelGGL(k_enc_ivl_ends, dim3((w.nivl + 255) / 256, w.nframes), dim3(256), 0, s, a);
+		hipLaunchKernelGGL(k_enc_ivl_scan, dim3(w.nframes), dim3(256), 0, s, a);
+		JH_T_END(th, s);
+	}
 	JH_T_BEGIN(th, "k_enc_pack", s);
 	hipLaunchKernelGGL(k_enc_pack, dim3(w.nwg, w.nframes), dim3(256), 0, s, a);
 	JH_T_END(th, s);

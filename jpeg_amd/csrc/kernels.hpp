@@ -112,7 +112,11 @@ struct JhEncodeWork {
 	int nframes;
 	int nwg;                      // workgroups (256 blocks each) per frame
 	int nchunk;                   // stuffing chunks per frame (capacity)
-	int restart_interval;         // MCUs, 0 = none
+	int restart_interval;         // MCUs, 0 = none (EXTENSION: the reference never writes DRI / RSTn)
+	int nivl;                     // restart intervals per frame (restart_interval > 0)
+	uint32_t *ivl_raw;            // [frame][nivl] entropy-coded bits up to the END of interval k, before padding
+	uint32_t *ivl_padsum;         // [frame][nivl + 1] padding bits (to byte boundaries) before interval k
+	uint32_t *ivl_eb;             // [frame][nivl] byte offset in the unstuffed stream at which interval k ends
 };
 
 int jh_launch_enc_histogram(const JhEncodeWork &w, const JhGeom &g, hipStream_t s, const JhTimerHook *th);

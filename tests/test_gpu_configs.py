@@ -29,9 +29,11 @@ def _run(hip, oracle, name, restart_interval=0, frames=1):
     # decode on the GPU (optionally the restart-marker variant of the same image, written by the oracle)
     src = jpgs
     if restart_interval:
+        # the restart-marker variant: GPU encoder (extension) == oracle, byte for byte
         err, rj, _ = oracle.encode(imgs[0], P=P, H=H, V=V, q=q, optimize=opt, restart_interval=restart_interval)
         assert err == 0
-        src = [rj] * frames
+        src, st = hip.encode(imgs, P=P, H=H, V=V, q=q, optimize=opt, restart_interval=restart_interval)
+        assert st == [0] * frames and src[0] == rj
     d = hip.Decoder()
     d.prepare(src)
     out = d.run()
@@ -48,8 +50,8 @@ def _run(hip, oracle, name, restart_interval=0, frames=1):
 
 
 def test_c2_4k_444_q90_restart_per_mcu_row(hip, oracle):
-    # 480 MCUs per row at 4:4:4: one restart interval per MCU row (the encoder side of restart
-    # markers is an extension; here the oracle writes them and the reference decoder is the judge)
+    # 480 MCUs per row at 4:4:4: one restart interval per MCU row, encode AND decode (the encoder side of
+    # restart markers is an extension of the reference; tests/test_gpu_parity.py has the reference decoder judge it)
     px, stats = _run(hip, oracle, "c2_4k_444_q90", restart_interval=480)
     assert stats[3] == 270                               # restart segments found
 

@@ -276,3 +276,24 @@ def test_motion_jpeg_stream_in_batches(hip, oracle):
     assert k == len(frames)
     tot = mjpeg.gather_stats({"frames": k, "bytes": 0, "checksum": mjpeg.combine_checksums(sums)})
     assert tot["frames"] == len(frames)
+
+
+def test_restart_marker_encode_extension(hip, oracle, reference):
+    """DRI / RSTn on the encoder side are an extension (the reference writes none).
+    The GPU encoder's stream equals the oracle's byte for byte, and the REFERENCE decoder (the judge of
+    this extension) decodes it to the same samples as the stream without restart markers."""
+    img = synth_image(200, 136, 3, 8, seed=11)
+    gray = synth_image(120, 72, 1, 8, seed=12)
+    cases = [(img, 2, 2, 1, 0), (img, 2, 2, 5, 1), (img, 2, 1, 13, 0), (img, 1, 1, 25, 1), (img, 2, 2, 1000, 0),
+             (gray, 1, 1, 4, 1)]
+    for im, H, V, ri, opt in cases:
+        jpgs, st = hip.encode([im, im], P=8, H=H, V=V, q=80, optimize=opt, restart_interval=ri)
+        assert st == [0, 0]
+        err, oj, _ = oracle.encode(im, P=8, H=H, V=V, q=80, optimize=opt, restart_interval=ri)
+        assert err == 0
+        assert jpgs[0] == oj and jpgs[1] == oj
+        err, plain, _ = oracle.encode(im, P=8, H=H, V=V, q=80, optimize=opt)
+        rerr, rpx, _ = reference.decode(jpgs[0])
+        assert rerr == 0 and np.array_equal(rpx, reference.decode(plain)[1])
+        outs, st = hip.decode(jpgs)
+        assert st == [0, 0] and np.array_equal(outs[0], rpx)
