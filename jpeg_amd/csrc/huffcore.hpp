@@ -5,9 +5,12 @@
 // the fast table yields (code length, zero run, category) with EOB pre-encoded as "run 63", so
 //     k = z + run;  coefficient k <- value;  z = k + 1;  z >= 64 ends the block
 // covers DC (z = 0, run = 0), (run, size) pairs, ZRL (run 15, category 0) and EOB without branches.
-// The bit stream is read through a small interface (LDS-staged window or global memory), the
-// 64-bit bit buffer is refilled one 32-bit word at a time and the next word is always in flight,
-// so the only load on the symbol-to-symbol critical path is the table look-up.
+// The bit stream is read through a small interface: RegStream (a queue of words in registers,
+// refilled by one 16-byte global load per four words, a quad ahead), LdsStream (staged window, kept
+// behind -DJH_LDS_STREAM for comparison) or GlobalStream (plain word loads, careful paths).  The bit
+// window is three 32-bit words in registers, and the NEXT symbol's table look-up is issued before
+// the current symbol's value is extracted, so no load sits on the symbol-to-symbol critical path
+// except that look-up.
 #pragma once
 
 #include <hip/hip_runtime.h>

@@ -11,18 +11,15 @@
 //        count -> scan -> scatter.  Output: one contiguous unstuffed bit stream per frame plus the
 //        byte offset at which every restart segment starts.  The ECS ends at the first FF xx with
 //        xx not in {00, D0..D7} (io.c:265-269).
-//   2. k_huff_sync_intra
+//   2. huffsync.hip: k_huff_chains / k_huff_walk / k_huff_finish
 //        the stream is cut into sub-sequences of JH_SUBSEQ_BITS bits, one thread each.  Every thread
-//        decodes its sub-sequence from the guess "a DC code of block 0 starts at my first bit" and
-//        records its exit state (bit position, block-in-MCU, zig-zag index).  Huffman streams
-//        self-synchronise: a wrong guess falls into step with the true parse after a few symbols.
-//        Threads then keep decoding into the following sub-sequences and overwrite the stored exit
-//        states until their own state equals the stored one (earlier-starting chains win; the first
-//        sub-sequence of a frame, and everything after a restart boundary, is known to be right).
-//   3. k_huff_sync_inter   the same across workgroup boundaries, iterated to a fixed point
-//   4. k_huff_scan         exclusive (restart-segmented) prefix sums of blocks and DC differences
-//   5. k_huff_write        every thread re-decodes its sub-sequence from its now-known entry state
-//                          and scatters coefficients (absolute DC) into the int16 scan-order buffer.
+//        decodes from the guess "a DC code of block 0 starts at my first bit"; Huffman streams
+//        self-synchronise, so a wrong guess falls into step with the true parse after a few symbols.
+//        The kernels find, for every sub-sequence, the state in which the TRUE parse enters it, and
+//        the (restart-segmented) prefix sums of blocks and DC differences up to it.
+//   3. k_huff_write   every thread re-decodes its sub-sequence from its now-known entry state,
+//                     assembles whole 128-byte blocks (absolute DC) in LDS and the wave stores them.
+//   4. k_coef_tail_clear   blocks the stream never reached are zero (common.c:129).
 //
 // A restart boundary inside a sub-sequence resets the state (c = z = 0, predictors 0) whatever the
 // state before was, so restart intervals and speculative decoding are ONE mechanism here: with
@@ -340,12 +337,14 @@ __device__ __forceinline__ void flush_blocks(bool fin, int fblk, int4 *bufs, int
 		const int sblk = __builtin_amdgcn_ds_bpermute(g << 2, pblk);
 		const int sthr = __builtin_amdgcn_ds_bpermute(g << 2, pthr);
 		if (g < n) {
-			const int phys = lane & 7;
-			int4 *src = bufs + sthr * 8 + phys;
+			// lane j of the group stores logical chunk j: the eight lanes write one whole 128-byte line
+			// in ascending order (rotated orders reach L2 as partial sectors, which it fills from HBM first)
+			const int j = lane & 7;
+			int4 *src = bufs + sthr * 8 + ((j + sthr) & 7);
 			const int4 v = *src;
 			*src = make_int4(0, 0, 0, 0);
 			if (sblk >= 0) {
-				frame_coefs[(size_t)sblk * 8 + ((phys - sthr) & 7)] = v;
+				frame_coefs[(size_t)sblk * 8 + j] = v;
 			}
 		}
 	}
