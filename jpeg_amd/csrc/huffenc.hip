@@ -31,7 +31,8 @@
 #include "common.hpp"
 #include "kernels.hpp"
 
-#define WIN_WORDS 6144                // LDS image of one workgroup's bit range: 24 KB = 768 bits/block
+#define WIN_WORDS 2048                // LDS image of one workgroup's bit range: 8 KB = 256 bits/block per pass
+#define ST_STRIDE 33                  // words per staged block (32 + 1: lanes reading one column hit 64 banks)
 #define FF_CHUNK 4096
 
 struct EncArgs {
@@ -387,120 +388,252 @@ __global__ __launch_bounds__(256) void k_enc_ivl_scan(const EncArgs a)
 
 // ---------------------------------------------------------------------------------------- bit packing
 
+// bit 0: the low int16 of d is nonzero, bit 1: the high one
+__device__ __forceinline__ unsigned nz_pair(int d)
+{
+	typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+	const us2 one = {1, 1};
+	const unsigned x = __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(us2, d), one));
+	return (x | (x >> 15)) & 3u;
+}
+
+// what a thread reads from global memory for one group of 256 blocks
+struct PackIn {
+	int4 chunk[8];                    // 16-byte pieces j * 256 + tid of the group's coefficients
+	uint32_t r0, r1;                  // the group's bit range
+	unsigned mylen, mypad;            // bits of this thread's block (padding of its restart interval included)
+	int pred;                         // DC predictor of this thread's block
+	uint32_t kt;                      // its ktab entry
+	bool have;
+};
+
+// per block k of an MCU: component | tables | where the DC predictor of the block is (encoder.c:443-458)
+#define KT_COMP(t) ((t) & 3u)
+#define KT_TD(t) (((t) >> 2) & 1u)
+#define KT_TA(t) (((t) >> 3) & 1u)
+#define KT_INNER(t) (((t) >> 4) & 1u)     // the predictor is the previous block of the same MCU
+#define KT_LASTK(t) (((t) >> 5) & 31u)    // k == B - 1
+#define KT_BACK(t) ((t) >> 16)            // blocks back to the predictor
+
+__device__ __forceinline__ uint32_t make_ktab(const JhGeom &g, int k)
+{
+	const int comp = g.blk_comp[k];
+	const int firstk = g.comp_first[comp];
+	const int lastk = firstk + g.H[comp] * g.V[comp] - 1;
+	const bool inner = k > firstk;
+	const int back = inner ? 1 : k + g.B - lastk;
+	return (uint32_t)comp | ((uint32_t)(g.Td[comp] & 1) << 2) | ((uint32_t)(g.Ta[comp] & 1) << 3) |
+	       ((uint32_t)inner << 4) | ((uint32_t)(k == g.B - 1) << 5) | ((uint32_t)back << 16);
+}
+
+// ktab lives in LDS: reading it does not wait for the global loads in flight
+__device__ __forceinline__ void pack_fetch(const EncArgs &a, const uint32_t *ktab, int f, int grp, int tid, PackIn &in)
+{
+	const JhEncodeWork &w = a.w;
+	const int B = a.g.B, nblk = a.g.nblk, nmcu = a.g.nmcu;
+	const uint32_t *wg = w.wg_bits + (size_t)f * (w.nwg + 1);
+	const int16_t *fc = w.coefs + (size_t)f * nblk * 64;
+	const int first = grp * 256, blk = first + tid;
+	const int ri = w.restart_interval;
+	in.have = blk < nblk;
+	// per-lane loads of the (uniform) range: a scalarised load would be waited for right here
+	int gi = grp;
+	asm volatile("" : "+v"(gi));
+	in.r0 = wg[gi];
+	in.r1 = wg[gi + 1];
+	in.mylen = in.have ? w.bitlen[(size_t)f * nblk + blk] : 0u;
+	const int mcu = blk / B, k = blk - mcu * B;
+	const uint32_t kt = ktab[in.have ? k : 0];
+	in.kt = kt;
+	in.pred = 0;
+	if (in.have && (KT_INNER(kt) || (mcu != 0 && !(ri > 0 && mcu % ri == 0)))) {
+		in.pred = fc[(size_t)(blk - (int)KT_BACK(kt)) * 64];
+	}
+	const int nchunk = min(256, nblk - first) * 8;
+	const int4 *src = reinterpret_cast<const int4 *>(fc + (size_t)first * 64);
+#pragma unroll
+	for (int j = 0; j < 8; ++j) {
+		const int ch = j * 256 + tid;
+		in.chunk[j] = ch < nchunk ? src[ch] : make_int4(0, 0, 0, 0);
+	}
+	in.mypad = 0;
+	if (ri > 0) {
+		// restart intervals (extension): everything moves by the padding before its interval, and the last
+		// block of an interval carries the interval's padding
+		const uint32_t *padsum = w.ivl_padsum + (size_t)f * (w.nivl + 1);
+		const int next = first + 256;
+		in.r0 += padsum[interval_of_block(first, B, ri)];
+		in.r1 += next < nblk ? padsum[interval_of_block(next, B, ri)] : padsum[w.nivl];
+		if (in.have && KT_LASTK(kt) && ((mcu + 1) % ri == 0 || mcu + 1 == nmcu)) {
+			const int iv = mcu / ri;
+			in.mypad = padsum[iv + 1] - padsum[iv];
+			in.mylen += in.mypad;
+		}
+	}
+}
+
+// A workgroup packs the groups blockIdx.x, blockIdx.x + gridDim.x, ... of 256 blocks.  A group is staged in
+// LDS (coalesced 16-byte loads, issued while the previous group is being packed) and a 64-bit map of the
+// nonzero coefficients of every block is built on the way; a thread then visits only the nonzero
+// coefficients of its block (Figure F.2 without the 63-step scan: the zero run is the distance to the
+// previous nonzero) and ORs its code words into an LDS image of the group's bit range.
 __global__ __launch_bounds__(256) void k_enc_pack(const EncArgs a)
 {
 	__shared__ uint32_t codes[4][256];
 	__shared__ unsigned scratch[4];
-	__shared__ uint32_t win[WIN_WORDS];
+	__shared__ __align__(16) uint32_t win[WIN_WORDS + 4];      // + sink
+	__shared__ uint32_t stage[256 * ST_STRIDE];
+	__shared__ __align__(8) uint8_t nzmap[256 * 8];
+	__shared__ uint32_t bstart[256], binfo[256], hist[64];
+	__shared__ int bpred[256];
+	__shared__ uint8_t owner[256];
 	const JhEncodeWork &w = a.w;
 	const JhGeom &g = a.g;
 	const int f = blockIdx.y;
 	if (w.state[f].status & JH_EST_OVERFLOW) {
 		return;
 	}
-	for (int i = threadIdx.x; i < 4 * 256; i += 256) {
-		(&codes[0][0])[i] = w.codes[(size_t)f * 4 + (i >> 8)].code[i & 255];
+	const int tid = threadIdx.x;
+	__shared__ uint32_t ktab[JH_MAX_MCU_BLOCKS];
+	if (tid < g.B) {
+		ktab[tid] = make_ktab(g, tid);
 	}
-	const uint32_t *wg = w.wg_bits + (size_t)f * (w.nwg + 1);
-	uint32_t r0 = wg[blockIdx.x], r1 = wg[blockIdx.x + 1];         // this workgroup's bit range
-	const int blk = blockIdx.x * 256 + threadIdx.x;
-	const int16_t *fc = w.coefs + (size_t)f * g.nblk * 64;
-	const bool have = blk < g.nblk;
-	unsigned mylen = have ? w.bitlen[(size_t)f * g.nblk + blk] : 0u;
-	const int ri = w.restart_interval;
-	unsigned mypad = 0;
-	if (ri > 0) {
-		// restart intervals (extension): everything moves by the padding before its interval, and the last
-		// block of an interval carries the interval's padding
-		const uint32_t *padsum = w.ivl_padsum + (size_t)f * (w.nivl + 1);
-		const int first = blockIdx.x * 256, next = first + 256;
-		r0 += padsum[interval_of_block(first, g.B, ri)];
-		r1 += next < g.nblk ? padsum[interval_of_block(next, g.B, ri)] : padsum[w.nivl];
-		if (have) {
-			const int mcu = blk / g.B;
-			if (blk - mcu * g.B == g.B - 1 && ((mcu + 1) % ri == 0 || mcu + 1 == g.nmcu)) {
-				const int k = mcu / ri;
-				mypad = padsum[k + 1] - padsum[k];
-				mylen += mypad;
-			}
-		}
+	__syncthreads();
+	PackIn in;
+	pack_fetch(a, ktab, f, blockIdx.x, tid, in);
+#pragma unroll
+	for (int j = 0; j < 4; ++j) {
+		codes[j][tid] = w.codes[(size_t)f * 4 + j].code[tid];
 	}
-	unsigned total;
-	const uint32_t start = r0 + block_excl(mylen, scratch, &total);   // barrier inside: codes[] visible after
-	if (r1 == r0) {
-		return;
+	for (int i = tid; i < WIN_WORDS / 4; i += 256) {
+		reinterpret_cast<int4 *>(win)[i] = make_int4(0, 0, 0, 0);
 	}
-	BlockRegs b;
-	int diff = 0, comp = 0;
-	if (have) {
-		load_block(fc + (size_t)blk * 64, b);
-		comp = g.blk_comp[blk % g.B];
-		diff = coef_at(b, 0) - dc_predictor(fc, blk, g, w.restart_interval);
-	}
-	const uint32_t *cd = codes[0 * 2 + (g.Td[comp] & 1)];
-	const uint32_t *ca = codes[1 * 2 + (g.Ta[comp] & 1)];
 	uint32_t *us = w.us + (size_t)f * (w.us_stride / 4);
 
-	const uint32_t wfirst = r0 >> 5, wlast = (r1 - 1) >> 5;
-	for (uint32_t wbase = wfirst; wbase <= wlast; wbase += WIN_WORDS) {
-		for (int i = threadIdx.x; i < WIN_WORDS; i += 256) {
-			win[i] = 0;
+	for (int grp = blockIdx.x; grp < w.nwg; grp += gridDim.x) {
+		// ---- stage the blocks, build the nonzero maps
+#pragma unroll
+		for (int j = 0; j < 8; ++j) {
+			const int ch = j * 256 + tid;
+			const int4 v = in.chunk[j];
+			uint32_t *row = stage + (ch >> 3) * ST_STRIDE + (ch & 7) * 4;
+			row[0] = (uint32_t)v.x;
+			row[1] = (uint32_t)v.y;
+			row[2] = (uint32_t)v.z;
+			row[3] = (uint32_t)v.w;
+			nzmap[ch] = (uint8_t)(nz_pair(v.x) | (nz_pair(v.y) << 2) | (nz_pair(v.z) << 4) | (nz_pair(v.w) << 6));
+		}
+		const uint32_t r0 = __builtin_amdgcn_readfirstlane(in.r0), r1 = __builtin_amdgcn_readfirstlane(in.r1);
+		const unsigned mylen = in.mylen, mypad = in.mypad;
+		const int pred = in.pred;
+		const uint32_t kt = in.kt;
+		const bool have = in.have;
+		// the next group's reads are in flight while this one is packed
+		if (grp + (int)gridDim.x < w.nwg) {
+			pack_fetch(a, ktab, f, grp + (int)gridDim.x, tid, in);
+		}
+		binfo[tid] = mylen | (mypad << 16) | (KT_TD(kt) << 20) | (KT_TA(kt) << 21) | ((uint32_t)have << 22);
+		bpred[tid] = pred;
+		if (tid < 64) {
+			hist[tid] = 0;
+		}
+		unsigned total;
+		bstart[tid] = r0 + block_excl(mylen, scratch, &total);            // barriers inside: LDS contents visible after
+		// ---- blocks change hands so that the blocks of a wave have similar numbers of nonzero coefficients
+		// (the wave walks as long as its busiest lane): counting sort by that number, busiest first
+		const int bin = 63 - __popcll(reinterpret_cast<const unsigned long long *>(nzmap)[tid] & ~1ull);
+		const unsigned rank = atomicAdd(&hist[bin], 1u);
+		__syncthreads();
+		{
+			const int lane = tid & 63;
+			const unsigned h = hist[lane];
+			unsigned inc = h;
+#pragma unroll
+			for (int o = 1; o < 64; o <<= 1) {
+				const unsigned t = __shfl_up(inc, o, 64);
+				inc += lane >= o ? t : 0u;
+			}
+			owner[__shfl(inc - h, bin, 64) + rank] = (uint8_t)tid;
 		}
 		__syncthreads();
-		// does my bit range [start, start + mylen) touch this window?
-		const uint32_t lo_bit = wbase << 5;
-		const unsigned long long hi_bit = ((unsigned long long)wbase + WIN_WORDS) << 5;
-		if (have && mylen && (unsigned long long)start + mylen > lo_bit && start < hi_bit) {
-			unsigned long long acc = 0;                    // bits collected, left aligned
-			int nacc = (int)(start & 31u);                 // the word's leading bits belong to my predecessor
-			uint32_t widx = start >> 5;
-			auto put = [&](unsigned code, int len) {       // len <= 31
-				if (len <= 0) {
-					return;                                // symbol without code: flagged by k_enc_bitlen
-				}
-				acc |= (unsigned long long)code << (64 - nacc - len);
-				nacc += len;
-				if (nacc >= 32) {
-					const uint32_t rel = widx - wbase;     // unsigned: words before the window wrap to huge
-					if (rel < WIN_WORDS) {
-						atomicOr(&win[rel], (uint32_t)(acc >> 32));
+		const int lb = owner[tid];                                         // the block this thread packs
+		const uint32_t start = bstart[lb], inf = binfo[lb];
+		const unsigned plen = inf & 0xffffu, ppad = (inf >> 16) & 15u;
+		const bool phave = (inf >> 22) & 1u;
+		const int16_t *mine = reinterpret_cast<const int16_t *>(stage + lb * ST_STRIDE);
+		const unsigned long long nzac = reinterpret_cast<const unsigned long long *>(nzmap)[lb] & ~1ull;
+		const int diff = phave ? (int)mine[0] - bpred[lb] : 0;
+		const uint32_t *cd = codes[0 * 2 + ((inf >> 20) & 1u)];
+		const uint32_t *ca = codes[1 * 2 + ((inf >> 21) & 1u)];
+
+		const uint32_t wfirst = r0 >> 5, wlast = r1 > r0 ? (r1 - 1) >> 5 : wfirst;
+		for (uint32_t wbase = wfirst; wbase <= wlast && r1 > r0; wbase += WIN_WORDS) {
+			// does my bit range [start, start + mylen) touch this window?
+			const uint32_t lo_bit = wbase << 5;
+			const unsigned long long hi_bit = ((unsigned long long)wbase + WIN_WORDS) << 5;
+			if (phave && plen && (unsigned long long)start + plen > lo_bit && start < hi_bit) {
+				// a symbol (at most 31 bits) is ORed into the two words it can touch; words outside this
+				// pass's window go to the sink behind it.  No accumulator, no branch.
+				uint32_t pos = start;
+				auto put = [&](unsigned code, unsigned len) {
+					const unsigned long long v = (unsigned long long)code << ((64u - (pos & 31u) - len) & 63u);
+					const uint32_t rel = (pos >> 5) - wbase;   // unsigned: words before the window wrap to huge
+					atomicOr(&win[min(rel, (uint32_t)WIN_WORDS)], (uint32_t)(v >> 32));
+					atomicOr(&win[min(rel + 1u, (uint32_t)WIN_WORDS)], (uint32_t)v);
+					pos += len;
+				};
+				const int dcat = category(diff) & 15;
+				const uint32_t dcode = cd[dcat];               // write_dc (coeffs.c:110-126)
+				put(((dcode >> 8) << dcat) | extra_bits(diff, dcat), (dcode & 0xffu) + dcat);
+				// write_ac (coeffs.c:164-194); the next nonzero coefficient is read while this one is emitted
+				unsigned long long m = nzac;
+				int prev = 0;
+				int k = m ? __builtin_ctzll(m) : 63;
+				int c = mine[k];
+				while (m) {
+					m &= m - 1;
+					const int kn = m ? __builtin_ctzll(m) : 63;
+					const int cn = mine[kn];
+					const int r = k - prev - 1;
+					prev = k;
+					if (r > 15) {
+						const uint32_t z = ca[0xf0];           // ZRL
+						for (int q = r >> 4; q > 0; --q) {
+							put(z >> 8, z & 0xffu);
+						}
 					}
-					acc <<= 32;
-					nacc -= 32;
-					widx++;
+					const int cat = category(c);
+					const uint32_t e = ca[((r & 15) << 4) | (cat & 15)];
+					put(((e >> 8) << cat) | extra_bits(c, cat), (e & 0xffu) + cat);
+					k = kn;
+					c = cn;
 				}
-			};
-			const int dcat = category(diff) & 15;
-			const uint32_t dcode = cd[dcat];               // write_dc (coeffs.c:110-126)
-			put(((dcode >> 8) << dcat) | extra_bits(diff, dcat), (int)(dcode & 0xffu) + dcat);
-			walk_ac(b, [&](int rs, int cat, unsigned extra) {   // write_ac (coeffs.c:164-194)
-				const uint32_t e = ca[rs];
-				put(((e >> 8) << cat) | extra, (int)(e & 0xffu) + cat);
-			});
-			if (mypad) {
-				put((1u << mypad) - 1u, (int)mypad);           // flush_bits at the end of a restart interval
-			}
-			if (nacc > 0) {
-				const uint32_t rel = widx - wbase;
-				if (rel < WIN_WORDS) {
-					atomicOr(&win[rel], (uint32_t)(acc >> 32));
+				if (prev != 63) {
+					const uint32_t e = ca[0];                  // EOB
+					put(e >> 8, e & 0xffu);
+				}
+				if (ppad) {
+					put((1u << ppad) - 1u, ppad);              // flush_bits at the end of a restart interval
 				}
 			}
-		}
-		__syncthreads();
-		// store the image: whole words plainly, the (at most two) words shared with neighbours by OR
-		const uint32_t nw = min((uint32_t)WIN_WORDS, wlast - wbase + 1);
-		for (uint32_t i = threadIdx.x; i < nw; i += 256) {
-			const uint32_t wi = wbase + i;
-			const uint32_t v = __builtin_bswap32(win[i]);  // MSB-first bit stream -> byte order
-			const bool whole = (wi << 5) >= r0 && ((unsigned long long)(wi + 1) << 5) <= r1;
-			if (whole) {
-				us[wi] = v;
-			} else if (v) {
-				atomicOr(&us[wi], v);
+			__syncthreads();
+			// store the image: whole words plainly, the (at most two) words shared with neighbours by OR; the
+			// image is left zero for the next pass
+			const uint32_t nw = min((uint32_t)WIN_WORDS, wlast - wbase + 1);
+			for (uint32_t i = tid; i < nw; i += 256) {
+				const uint32_t wi = wbase + i;
+				const uint32_t v = __builtin_bswap32(win[i]);  // MSB-first bit stream -> byte order
+				win[i] = 0;
+				const bool whole = (wi << 5) >= r0 && ((unsigned long long)(wi + 1) << 5) <= r1;
+				if (whole) {
+					us[wi] = v;
+				} else if (v) {
+					atomicOr(&us[wi], v);
+				}
 			}
+			__syncthreads();
 		}
-		__syncthreads();
+		__syncthreads();                                   // stage[] and nzmap[] are rewritten next
 	}
 }
 
@@ -665,7 +798,9 @@ int jh_launch_enc_entropy(const JhEncodeWork &w, const JhGeom &g, hipStream_t s,
 		JH_T_END(th, s);
 	}
 	JH_T_BEGIN(th, "k_enc_pack", s);
-	hipLaunchKernelGGL(k_enc_pack, dim3(w.nwg, w.nframes), dim3(256), 0, s, a);
+	// a workgroup packs several groups of 256 blocks in turn when the frame has plenty of them
+	const int pack_wgs = w.nwg >= 64 ? (w.nwg + 3) / 4 : w.nwg;
+	hipLaunchKernelGGL(k_enc_pack, dim3(pack_wgs, w.nframes), dim3(256), 0, s, a);
 	JH_T_END(th, s);
 	JH_T_BEGIN(th, "k_enc_ffcount", s);
 	hipLaunchKernelGGL(k_enc_ffcount, dim3(w.nchunk, w.nframes), dim3(256), 0, s, a);
