@@ -145,29 +145,55 @@ struct StageTimer {
 
 // ======================================================================================= decoder
 
-struct jpeg_hip_decoder {
-	int device = 0;
-	int nframes = 0;
-	JhGeom g;
+// One scan of every frame of the batch: its own unstuffed streams, synchronisation records and states.
+// Frames whose single scan interleaves all components have one pass; frames coded as one scan per
+// component (non-interleaved, decoder.c:274-302) have one pass per scan.  The raw codestreams, the
+// quantisation tables and the coefficient buffer are shared.
+struct DecPass {
+	JhGeom g;                         // what the Huffman kernels see (B = 1 for a single-component scan)
+	int comp = -1;                    // component of a single-component scan, -1 = all (interleaved)
 	std::vector<JhDecFrame> frames;
 	std::vector<JhDecState> state;
-	std::vector<int> parse_err;
-	std::vector<size_t> ecs_len;
-	// device
-	uint8_t *d_raw = nullptr, *d_cs = nullptr;
+	uint8_t *d_cs = nullptr;
 	uint32_t *d_seg = nullptr, *d_chunk_kept = nullptr, *d_chunk_rst = nullptr;
 	JhSubInfo *d_rec = nullptr, *d_prec = nullptr;
 	unsigned long long *d_wg_key = nullptr;
 	uint32_t *d_meta = nullptr;
 	JhWgAgg *d_wg_agg = nullptr, *d_wg_base = nullptr;
 	JhSubStart *d_start = nullptr;
+	unsigned long long *d_drop = nullptr;
 	JhDecFrame *d_frames = nullptr;
 	JhDecState *d_state = nullptr;
 	JhHuffLut *d_luts = nullptr;
+	std::vector<JhHuffLut> luts;
+	size_t cs_off = 0, seg_off = 0, chunk_off = 0, sub_off = 0, wg_off = 0;
+	uint32_t max_chunks = 1, max_subs = 1, max_luts = 1;
+	JhDecodeWork work;
+
+	void release()
+	{
+		hipFree(d_cs); hipFree(d_seg); hipFree(d_chunk_kept); hipFree(d_chunk_rst);
+		hipFree(d_start); hipFree(d_frames); hipFree(d_state); hipFree(d_luts);
+		hipFree(d_rec); hipFree(d_meta); hipFree(d_wg_agg); hipFree(d_wg_base); hipFree(d_prec); hipFree(d_wg_key); hipFree(d_drop);
+		d_drop = nullptr;
+		d_cs = nullptr; d_seg = d_chunk_kept = d_chunk_rst = nullptr;
+		d_start = nullptr; d_frames = nullptr; d_state = nullptr; d_luts = nullptr;
+		d_rec = d_prec = nullptr; d_meta = nullptr; d_wg_agg = d_wg_base = nullptr; d_wg_key = nullptr;
+	}
+};
+
+struct jpeg_hip_decoder {
+	int device = 0;
+	int nframes = 0;
+	JhGeom g;
+	std::vector<DecPass> pass;
+	std::vector<int> parse_err;
+	std::vector<size_t> ecs_len;
+	// device
+	uint8_t *d_raw = nullptr;
 	JhQuant *d_quant = nullptr;
 	int16_t *d_coefs = nullptr;
-	size_t raw_bytes = 0, cs_bytes = 0, seg_entries = 0, chunk_entries = 0, sub_entries = 0;
-	JhDecodeWork work;
+	size_t raw_bytes = 0;
 	void *last_out = nullptr;
 	size_t last_stride = 0;
 	hipStream_t last_stream = nullptr;
@@ -177,14 +203,12 @@ struct jpeg_hip_decoder {
 
 	void release()
 	{
-		hipFree(d_raw); hipFree(d_cs); hipFree(d_seg); hipFree(d_chunk_kept); hipFree(d_chunk_rst);
-		hipFree(d_start); hipFree(d_frames); hipFree(d_state); hipFree(d_luts);
-		hipFree(d_quant); hipFree(d_coefs); hipFree(d_rec); hipFree(d_meta); hipFree(d_wg_agg); hipFree(d_wg_base); hipFree(d_prec); hipFree(d_wg_key);
-		d_prec = nullptr; d_wg_key = nullptr;
-		d_rec = nullptr; d_meta = nullptr; d_wg_agg = d_wg_base = nullptr;
-		d_raw = d_cs = nullptr; d_seg = d_chunk_kept = d_chunk_rst = nullptr;
-		d_start = nullptr; d_frames = nullptr; d_state = nullptr; d_luts = nullptr;
-		d_quant = nullptr; d_coefs = nullptr;
+		for (DecPass &p : pass) {
+			p.release();
+		}
+		pass.clear();
+		hipFree(d_raw); hipFree(d_quant); hipFree(d_coefs);
+		d_raw = nullptr; d_quant = nullptr; d_coefs = nullptr;
 	}
 };
 
@@ -224,6 +248,77 @@ static bool same_geometry(const JhGeom &a, const JhGeom &b)
 	return true;
 }
 
+// one scan of one frame as the host found it
+struct ScanDesc {
+	int comp;                         // -1: all components interleaved
+	size_t ecs_begin, ecs_end;        // ecs_end: end of the bytes the device may look at
+	int Td[JH_MAX_COMP], Ta[JH_MAX_COMP];
+	JhHuffSpec ht[2][4];              // the tables in force when the scan started
+	int Ri;
+};
+
+// SOI .. EOI of one frame: headers, and the list of scans.  Tables may be redefined between scans
+// (decoder.c:581-591 runs whenever a DHT comes); quantisation tables count as they stand at EOI,
+// where the reference dequantises (decoder.c:456-470).
+static int parse_frame(const uint8_t *p, size_t n, JhHeader *h, std::vector<ScanDesc> *scans)
+{
+	scans->clear();
+	int err = jh_parse_headers(p, n, h);
+	if (err) {
+		return err;
+	}
+	auto describe = [&](int comp, size_t end) {
+		ScanDesc sd;
+		sd.comp = comp;
+		sd.ecs_begin = h->ecs_offset;
+		sd.ecs_end = end;
+		for (int k = 0; k < JH_MAX_COMP; ++k) {
+			sd.Td[k] = h->g.Td[k];
+			sd.Ta[k] = h->g.Ta[k];
+		}
+		memcpy(sd.ht, h->ht, sizeof sd.ht);
+		sd.Ri = h->g.Ri;
+		scans->push_back(sd);
+	};
+	if (h->Ns == h->g.ncomp) {
+		// one scan with every component: the device finds its end (no host pass over the data)
+		for (int j = 0; j < h->Ns; ++j) {
+			h->g.scan_order[j] = h->scan_comp[j];
+		}
+		describe(-1, n);
+		return RET_SUCCESS;
+	}
+	// one component per scan; scans of 2 .. Nf-1 components are not on the GPU path
+	unsigned seen = 0;
+	for (;;) {
+		if (h->Ns != 1) {
+			return RET_FAILURE_FILE_UNSUPPORTED;
+		}
+		const int k = h->scan_comp[0];
+		if (seen & (1u << k)) {
+			return RET_FAILURE_FILE_UNSUPPORTED;           // a component coded twice
+		}
+		seen |= 1u << k;
+		const size_t end = jh_ecs_end(p, n, h->ecs_offset);
+		if (end >= n) {
+			return RET_FAILURE_FILE_IO;                    // no marker after the data (io.c:197)
+		}
+		describe(k, end + 2);
+		bool eoi = false;
+		err = jh_parse_next_scan(p, n, end, h, &eoi);
+		if (err) {
+			return err;
+		}
+		if (eoi) {
+			break;
+		}
+	}
+	for (int j = 0; j < h->g.ncomp; ++j) {
+		h->g.scan_order[j] = j;                            // buffer order: components in frame order
+	}
+	return RET_SUCCESS;
+}
+
 extern "C" int jpeg_hip_decoder_prepare(jpeg_hip_decoder *dec, int nframes,
                                         const uint8_t *const *jpg, const size_t *jpg_len)
 {
@@ -234,33 +329,20 @@ extern "C" int jpeg_hip_decoder_prepare(jpeg_hip_decoder *dec, int nframes,
 	dec->release();
 	dec->ran = false;
 	dec->nframes = nframes;
-	dec->frames.assign(nframes, JhDecFrame());
-	dec->state.assign(nframes, JhDecState());
 	dec->parse_err.assign(nframes, 0);
 	dec->ecs_len.assign(nframes, 0);
 
 	std::vector<JhHeader> hdr(nframes);
-	std::vector<JhHuffLut> luts;
+	std::vector<std::vector<ScanDesc>> scans(nframes);
 	std::vector<JhQuant> quant(nframes);
-	bool have_geom = false;
-	size_t raw_off = 0, cs_off = 0, seg_off = 0, chunk_off = 0, sub_off = 0, wg_off = 0;
-	uint32_t max_chunks = 1, max_subs = 1, max_luts = 1;
 	std::vector<size_t> file_off(nframes);
+	std::vector<int> pass_comp;                            // the batch's scan structure (from the first good frame)
+	bool have_geom = false;
+	size_t raw_off = 0;
 
 	for (int f = 0; f < nframes; ++f) {
 		JhHeader &h = hdr[f];
-		int err = jh_parse_headers(jpg[f], jpg_len[f], &h);
-		if (!err) {
-			// the GPU path handles one scan that interleaves all components in frame order
-			// (everything the reference encoder and baseline encoders emit); the reference's
-			// multi-scan walk (decoder.c:274-302 on colour files) is listed under "next".
-			if (h.Ns != h.g.ncomp) {
-				err = RET_FAILURE_FILE_UNSUPPORTED;
-			}
-			for (int j = 0; j < h.Ns && !err; ++j) {
-				h.g.scan_order[j] = h.scan_comp[j];
-			}
-		}
+		int err = parse_frame(jpg[f], jpg_len[f], &h, &scans[f]);
 		if (!err) {
 			err = jh_finish_geometry(&h.g);
 		}
@@ -268,90 +350,32 @@ extern "C" int jpeg_hip_decoder_prepare(jpeg_hip_decoder *dec, int nframes,
 			if (!have_geom) {
 				dec->g = h.g;
 				have_geom = true;
-			} else if (!same_geometry(dec->g, h.g)) {
-				err = RET_FAILURE_FILE_UNSUPPORTED;   // one batch = one geometry
+				for (const ScanDesc &sd : scans[f]) {
+					pass_comp.push_back(sd.comp);
+				}
+			} else {
+				// one batch = one geometry and one scan structure
+				bool same = same_geometry(dec->g, h.g) && scans[f].size() == pass_comp.size();
+				for (size_t i = 0; same && i < pass_comp.size(); ++i) {
+					same = scans[f][i].comp == pass_comp[i];
+				}
+				if (!same) {
+					err = RET_FAILURE_FILE_UNSUPPORTED;
+				}
 			}
 		}
 		dec->parse_err[f] = err;
 		file_off[f] = raw_off;
-		JhDecFrame &fr = dec->frames[f];
-		memset(&fr, 0, sizeof fr);
-		if (err) {
-			// keep a harmless empty frame so that the grids stay rectangular
-			fr.raw_begin = fr.raw_end = (uint32_t)raw_off;
-			fr.cs_off = (uint32_t)cs_off;
-			fr.sub_off = (uint32_t)sub_off;
-			fr.sub_cap = 1;
-			fr.seg_off = (uint32_t)seg_off;
-			fr.seg_cap = 4;
-			fr.chunk_off = (uint32_t)chunk_off;
-			fr.nchunk = 0;
-			fr.lut_off = (uint32_t)luts.size();
-			fr.n_lut = 0;
-			fr.wg_off = (uint32_t)wg_off;
-			wg_off += 2;
-			cs_off += 64;
-			sub_off += 1;
-			seg_off += 4;
-			continue;
-		}
-		const size_t flen = jpg_len[f];
-		fr.raw_begin = (uint32_t)(raw_off + h.ecs_offset);
-		fr.raw_end = (uint32_t)(raw_off + flen);
-		const size_t ecs = flen - h.ecs_offset;
-		if (ecs > 0x1ffffff0ull) {
-			return RET_FAILURE_OVERFLOW_ERROR;               // bit positions are 32-bit: < 512 MB of entropy-coded data per frame
-		}
-		fr.cs_off = (uint32_t)cs_off;
-		const size_t cs_cap = align_up(ecs + 32 + 1024, 64);     // staging reads some words past the end
-		fr.sub_off = (uint32_t)sub_off;
-		fr.sub_cap = (uint32_t)(cs_cap / JH_SUBSEQ_BYTES + 2);
-		fr.seg_off = (uint32_t)seg_off;
-		const int Ri = h.g.Ri;
-		fr.seg_cap = (uint32_t)((Ri > 0 ? (h.g.nmcu + Ri - 1) / Ri : 1) + 64);
-		fr.chunk_off = (uint32_t)chunk_off;
-		fr.wg_off = (uint32_t)wg_off;
-		wg_off += fr.sub_cap / JH_SEQ_OWN + 2;
-		fr.nchunk = (uint32_t)((fr.raw_end + 4095) / 4096 - fr.raw_begin / 4096);
-		// Huffman tables used by this frame's scan -> LDS slots
-		int slot_of[2][4] = {{-1, -1, -1, -1}, {-1, -1, -1, -1}};
-		fr.lut_off = (uint32_t)luts.size();
-		for (int k = 0; k < h.g.ncomp && !err; ++k) {
-			const int ids[2] = {h.g.Td[k], h.g.Ta[k]};
-			for (int tc = 0; tc < 2 && !err; ++tc) {
-				if (slot_of[tc][ids[tc]] < 0) {
-					JhHuffLut l;
-					err = jh_build_declut(&h.ht[tc][ids[tc]], tc, &l);
-					slot_of[tc][ids[tc]] = (int)fr.n_lut++;
-					luts.push_back(l);
+		if (!err) {
+			for (int t = 0; t < 4; ++t) {
+				for (int z = 0; z < 64; ++z) {
+					quant[f].q[t][z] = h.Q[t][jh_zigzag[z]];
 				}
 			}
-		}
-		if (err) {
-			dec->parse_err[f] = err;
-			fr.nchunk = 0;
-			fr.raw_end = fr.raw_begin;
-		}
-		for (int b = 0; b < h.g.B; ++b) {
-			const int k = h.g.blk_comp[b];
-			fr.blk_dc[b] = (uint8_t)slot_of[0][h.g.Td[k]];
-			fr.blk_ac[b] = (uint8_t)slot_of[1][h.g.Ta[k]];
-		}
-		for (int t = 0; t < 4; ++t) {
-			for (int z = 0; z < 64; ++z) {
-				quant[f].q[t][z] = h.Q[t][jh_zigzag[z]];
+			raw_off = align_up(raw_off + jpg_len[f] + 32, 4096);   // chunk aligned: frames never share a chunk
+			if (raw_off > 0xf0000000ull) {
+				return RET_FAILURE_OVERFLOW_ERROR;               // 32-bit offsets: split the batch
 			}
-		}
-		max_chunks = fr.nchunk > max_chunks ? fr.nchunk : max_chunks;
-		max_subs = fr.sub_cap > max_subs ? fr.sub_cap : max_subs;
-		max_luts = fr.n_lut > max_luts ? fr.n_lut : max_luts;
-		raw_off = align_up(raw_off + flen + 32, 4096);   // chunk aligned: frames never share a chunk
-		cs_off += cs_cap;
-		sub_off += fr.sub_cap;
-		seg_off += fr.seg_cap;
-		chunk_off += fr.nchunk;
-		if (raw_off > 0xf0000000ull || cs_off > 0xf0000000ull) {
-			return RET_FAILURE_OVERFLOW_ERROR;               // 32-bit offsets: split the batch
 		}
 	}
 	if (!have_geom) {
@@ -362,68 +386,179 @@ extern "C" int jpeg_hip_decoder_prepare(jpeg_hip_decoder *dec, int nframes,
 		raw_off = 4096;
 	}
 	dec->raw_bytes = raw_off + 4096;
-	dec->cs_bytes = cs_off + 64;
-	dec->seg_entries = seg_off + 4;
-	dec->chunk_entries = chunk_off + 4;
-	dec->sub_entries = sub_off + 4;
-	if (luts.empty()) {
-		luts.push_back(JhHuffLut());
+	const JhGeom &G = dec->g;
+
+	dec->pass.resize(pass_comp.size());
+	for (size_t pi = 0; pi < pass_comp.size(); ++pi) {
+		DecPass &ps = dec->pass[pi];
+		ps.comp = pass_comp[pi];
+		ps.g = G;
+		JhRemap rm;
+		memset(&rm, 0, sizeof rm);
+		rm.nblk_full = G.nblk;
+		if (ps.comp >= 0) {
+			const int k = ps.comp;
+			// the reference's "MCU" of such a scan is H x V consecutive raster blocks (decoder.c:283-289):
+			// that is the unit dropped when an interval ends inside it, so it is the unit here as well
+			ps.g.B = G.H[k] * G.V[k];
+			for (int b = 0; b < ps.g.B; ++b) {
+				ps.g.blk_comp[b] = 0;
+			}
+			ps.g.nblk = G.bx[k] * G.by[k];
+			ps.g.nmcu = ps.g.nblk / ps.g.B;
+			rm.mode = 1;
+			rm.bxc = G.bx[k];
+			rm.H = G.H[k];
+			rm.V = G.V[k];
+			rm.m_x = G.m_x;
+			rm.B = G.B;
+			rm.kfirst = G.comp_first[k];
+		}
+		ps.frames.assign(nframes, JhDecFrame());
+		ps.state.assign(nframes, JhDecState());
+		for (int f = 0; f < nframes; ++f) {
+			JhDecFrame &fr = ps.frames[f];
+			memset(&fr, 0, sizeof fr);
+			int err = dec->parse_err[f];
+			if (err) {
+				// keep a harmless empty frame so that the grids stay rectangular
+				fr.raw_begin = fr.raw_end = (uint32_t)file_off[f];
+				fr.cs_off = (uint32_t)ps.cs_off;
+				fr.sub_off = (uint32_t)ps.sub_off;
+				fr.sub_cap = 1;
+				fr.seg_off = (uint32_t)ps.seg_off;
+				fr.seg_cap = 4;
+				fr.chunk_off = (uint32_t)ps.chunk_off;
+				fr.nchunk = 0;
+				fr.lut_off = (uint32_t)ps.luts.size();
+				fr.n_lut = 0;
+				fr.wg_off = (uint32_t)ps.wg_off;
+				ps.wg_off += 2;
+				ps.cs_off += 64;
+				ps.sub_off += 1;
+				ps.seg_off += 4;
+				continue;
+			}
+			const ScanDesc &sd = scans[f][pi];
+			fr.raw_begin = (uint32_t)(file_off[f] + sd.ecs_begin);
+			fr.raw_end = (uint32_t)(file_off[f] + sd.ecs_end);
+			const size_t ecs = sd.ecs_end - sd.ecs_begin;
+			if (ecs > 0x1ffffff0ull) {
+				return RET_FAILURE_OVERFLOW_ERROR;               // bit positions are 32-bit: < 512 MB of entropy-coded data per scan
+			}
+			fr.cs_off = (uint32_t)ps.cs_off;
+			const size_t cs_cap = align_up(ecs + 32 + 1024, 64);     // the stream readers look some words past the end
+			fr.sub_off = (uint32_t)ps.sub_off;
+			fr.sub_cap = (uint32_t)(cs_cap / JH_SUBSEQ_BYTES + 2);
+			fr.seg_off = (uint32_t)ps.seg_off;
+			fr.seg_cap = (uint32_t)((sd.Ri > 0 ? (ps.g.nmcu + sd.Ri - 1) / sd.Ri : 1) + 64);
+			fr.chunk_off = (uint32_t)ps.chunk_off;
+			fr.wg_off = (uint32_t)ps.wg_off;
+			ps.wg_off += fr.sub_cap / JH_SEQ_OWN + 2;
+			fr.nchunk = (uint32_t)((fr.raw_end + 4095) / 4096 - fr.raw_begin / 4096);
+			// Huffman tables used by this scan -> LDS slots
+			int slot_of[2][4] = {{-1, -1, -1, -1}, {-1, -1, -1, -1}};
+			fr.lut_off = (uint32_t)ps.luts.size();
+			const int k0 = ps.comp >= 0 ? ps.comp : 0, k1 = ps.comp >= 0 ? ps.comp + 1 : G.ncomp;
+			for (int k = k0; k < k1 && !err; ++k) {
+				const int ids[2] = {sd.Td[k], sd.Ta[k]};
+				for (int tc = 0; tc < 2 && !err; ++tc) {
+					if (slot_of[tc][ids[tc]] < 0) {
+						JhHuffLut l;
+						err = jh_build_declut(&sd.ht[tc][ids[tc]], tc, &l);
+						slot_of[tc][ids[tc]] = (int)fr.n_lut++;
+						ps.luts.push_back(l);
+					}
+				}
+			}
+			if (err) {
+				dec->parse_err[f] = err;
+				fr.nchunk = 0;
+				fr.raw_end = fr.raw_begin;
+			}
+			for (int b = 0; b < ps.g.B; ++b) {
+				const int k = ps.comp >= 0 ? ps.comp : G.blk_comp[b];
+				fr.blk_dc[b] = (uint8_t)slot_of[0][sd.Td[k]];
+				fr.blk_ac[b] = (uint8_t)slot_of[1][sd.Ta[k]];
+			}
+			ps.max_chunks = fr.nchunk > ps.max_chunks ? fr.nchunk : ps.max_chunks;
+			ps.max_subs = fr.sub_cap > ps.max_subs ? fr.sub_cap : ps.max_subs;
+			ps.max_luts = fr.n_lut > ps.max_luts ? fr.n_lut : ps.max_luts;
+			ps.cs_off += cs_cap;
+			ps.sub_off += fr.sub_cap;
+			ps.seg_off += fr.seg_cap;
+			ps.chunk_off += fr.nchunk;
+			if (ps.cs_off > 0xf0000000ull) {
+				return RET_FAILURE_OVERFLOW_ERROR;               // 32-bit offsets: split the batch
+			}
+		}
+		if (ps.luts.empty()) {
+			ps.luts.push_back(JhHuffLut());
+		}
+		const size_t cs_bytes = ps.cs_off + 64, seg_entries = ps.seg_off + 4, chunk_entries = ps.chunk_off + 4;
+		const size_t sub_entries = ps.sub_off + 4, wg_entries = ps.wg_off + 4;
+		HIPCHK(hipMalloc((void **)&ps.d_cs, cs_bytes));
+		HIPCHK(hipMalloc((void **)&ps.d_seg, seg_entries * 4));
+		HIPCHK(hipMalloc((void **)&ps.d_chunk_kept, chunk_entries * 4));
+		HIPCHK(hipMalloc((void **)&ps.d_chunk_rst, chunk_entries * 4));
+		HIPCHK(hipMalloc((void **)&ps.d_start, sub_entries * sizeof(JhSubStart)));
+		HIPCHK(hipMalloc((void **)&ps.d_rec, sub_entries * (JH_CHAIN_MAX + 1) * sizeof(JhSubInfo)));
+		HIPCHK(hipMalloc((void **)&ps.d_meta, sub_entries * sizeof(uint32_t)));
+		HIPCHK(hipMalloc((void **)&ps.d_prec, sub_entries * sizeof(JhSubInfo)));
+		HIPCHK(hipMalloc((void **)&ps.d_wg_key, wg_entries * sizeof(unsigned long long)));
+		HIPCHK(hipMalloc((void **)&ps.d_wg_agg, wg_entries * sizeof(JhWgAgg)));
+		HIPCHK(hipMalloc((void **)&ps.d_wg_base, wg_entries * sizeof(JhWgAgg)));
+		HIPCHK(hipMemset(ps.d_meta, 0, sub_entries * sizeof(uint32_t)));
+		HIPCHK(hipMemset(ps.d_wg_agg, 0, wg_entries * sizeof(JhWgAgg)));
+		HIPCHK(hipMemset(ps.d_wg_base, 0, wg_entries * sizeof(JhWgAgg)));
+		HIPCHK(hipMalloc((void **)&ps.d_frames, nframes * sizeof(JhDecFrame)));
+		HIPCHK(hipMalloc((void **)&ps.d_state, nframes * sizeof(JhDecState)));
+		HIPCHK(hipMalloc((void **)&ps.d_luts, ps.luts.size() * sizeof(JhHuffLut)));
+		HIPCHK(hipMemset(ps.d_cs, 0, cs_bytes));
+		HIPCHK(hipMemset(ps.d_seg, 0, seg_entries * 4));
+		HIPCHK(hipMalloc((void **)&ps.d_drop, seg_entries * sizeof(unsigned long long)));
+		HIPCHK(hipMemset(ps.d_drop, 0, seg_entries * sizeof(unsigned long long)));
+		HIPCHK(hipMemcpy(ps.d_frames, ps.frames.data(), nframes * sizeof(JhDecFrame), hipMemcpyHostToDevice));
+		HIPCHK(hipMemcpy(ps.d_luts, ps.luts.data(), ps.luts.size() * sizeof(JhHuffLut), hipMemcpyHostToDevice));
+		ps.work.rm = rm;
 	}
 
 	HIPCHK(hipMalloc((void **)&dec->d_raw, dec->raw_bytes));
-	HIPCHK(hipMalloc((void **)&dec->d_cs, dec->cs_bytes));
-	HIPCHK(hipMalloc((void **)&dec->d_seg, dec->seg_entries * 4));
-	HIPCHK(hipMalloc((void **)&dec->d_chunk_kept, dec->chunk_entries * 4));
-	HIPCHK(hipMalloc((void **)&dec->d_chunk_rst, dec->chunk_entries * 4));
-	HIPCHK(hipMalloc((void **)&dec->d_start, dec->sub_entries * sizeof(JhSubStart)));
-	HIPCHK(hipMalloc((void **)&dec->d_rec, dec->sub_entries * (JH_CHAIN_MAX + 1) * sizeof(JhSubInfo)));
-	HIPCHK(hipMalloc((void **)&dec->d_meta, dec->sub_entries * sizeof(uint32_t)));
-	HIPCHK(hipMalloc((void **)&dec->d_prec, dec->sub_entries * sizeof(JhSubInfo)));
-	HIPCHK(hipMalloc((void **)&dec->d_wg_key, (wg_off + 4) * sizeof(unsigned long long)));
-	HIPCHK(hipMalloc((void **)&dec->d_wg_agg, (wg_off + 4) * sizeof(JhWgAgg)));
-	HIPCHK(hipMalloc((void **)&dec->d_wg_base, (wg_off + 4) * sizeof(JhWgAgg)));
-	HIPCHK(hipMemset(dec->d_meta, 0, dec->sub_entries * sizeof(uint32_t)));
-	HIPCHK(hipMemset(dec->d_wg_agg, 0, (wg_off + 4) * sizeof(JhWgAgg)));
-	HIPCHK(hipMemset(dec->d_wg_base, 0, (wg_off + 4) * sizeof(JhWgAgg)));
-	HIPCHK(hipMalloc((void **)&dec->d_frames, nframes * sizeof(JhDecFrame)));
-	HIPCHK(hipMalloc((void **)&dec->d_state, nframes * sizeof(JhDecState)));
-	HIPCHK(hipMalloc((void **)&dec->d_luts, luts.size() * sizeof(JhHuffLut)));
 	HIPCHK(hipMalloc((void **)&dec->d_quant, nframes * sizeof(JhQuant)));
-	HIPCHK(hipMalloc((void **)&dec->d_coefs, (size_t)nframes * dec->g.nblk * 64 * sizeof(int16_t)));
+	HIPCHK(hipMalloc((void **)&dec->d_coefs, (size_t)nframes * G.nblk * 64 * sizeof(int16_t)));
 	HIPCHK(hipMemset(dec->d_raw, 0, dec->raw_bytes));
-	HIPCHK(hipMemset(dec->d_cs, 0, dec->cs_bytes));
-	HIPCHK(hipMemset(dec->d_seg, 0, dec->seg_entries * 4));
 	for (int f = 0; f < nframes; ++f) {
 		if (dec->parse_err[f] == 0) {
 			HIPCHK(hipMemcpy(dec->d_raw + file_off[f], jpg[f], jpg_len[f], hipMemcpyHostToDevice));
 		}
 	}
-	HIPCHK(hipMemcpy(dec->d_frames, dec->frames.data(), nframes * sizeof(JhDecFrame), hipMemcpyHostToDevice));
-	HIPCHK(hipMemcpy(dec->d_luts, luts.data(), luts.size() * sizeof(JhHuffLut), hipMemcpyHostToDevice));
 	HIPCHK(hipMemcpy(dec->d_quant, quant.data(), nframes * sizeof(JhQuant), hipMemcpyHostToDevice));
 
-	JhDecodeWork &w = dec->work;
-	w.raw = dec->d_raw;
-	w.cs = dec->d_cs;
-	w.seg_start = dec->d_seg;
-	w.chunk_kept = dec->d_chunk_kept;
-	w.chunk_rst = dec->d_chunk_rst;
-	w.rec = dec->d_rec;
-	w.meta = dec->d_meta;
-	w.prec = dec->d_prec;
-	w.wg_key = dec->d_wg_key;
-	w.wg_agg = dec->d_wg_agg;
-	w.wg_base = dec->d_wg_base;
-	w.start = dec->d_start;
-	w.frames = dec->d_frames;
-	w.state = dec->d_state;
-	w.luts = dec->d_luts;
-	w.coefs = dec->d_coefs;
-	w.nframes = nframes;
-	w.max_chunks = max_chunks;
-	w.max_subs = max_subs;
-	w.max_luts = max_luts;
-	w.debug = dec->debug;
+	for (DecPass &ps : dec->pass) {
+		JhDecodeWork &w = ps.work;
+		w.raw = dec->d_raw;
+		w.cs = ps.d_cs;
+		w.seg_start = ps.d_seg;
+		w.chunk_kept = ps.d_chunk_kept;
+		w.chunk_rst = ps.d_chunk_rst;
+		w.rec = ps.d_rec;
+		w.meta = ps.d_meta;
+		w.prec = ps.d_prec;
+		w.wg_key = ps.d_wg_key;
+		w.wg_agg = ps.d_wg_agg;
+		w.wg_base = ps.d_wg_base;
+		w.start = ps.d_start;
+		w.drop = ps.d_drop;
+		w.frames = ps.d_frames;
+		w.state = ps.d_state;
+		w.luts = ps.d_luts;
+		w.coefs = dec->d_coefs;
+		w.nframes = nframes;
+		w.max_chunks = ps.max_chunks;
+		w.max_subs = ps.max_subs;
+		w.max_luts = ps.max_luts;
+		w.debug = dec->debug;
+	}
 	return RET_SUCCESS;
 }
 
@@ -455,14 +590,21 @@ __global__ void k_dec_init(JhDecState *st, int n)
 
 static int decoder_launch(jpeg_hip_decoder *dec, hipStream_t s)
 {
-	const JhDecodeWork &w = dec->work;
 	const JhTimerHook th = dec->timer.hook();
-	hipLaunchKernelGGL(k_dec_init, dim3((dec->nframes + 63) / 64), dim3(64), 0, s, dec->d_state, dec->nframes);
-	if (jh_launch_ecs_unstuff(w, s, &th)) {
-		return RET_FAILURE_LOGIC_ERROR;
+	if (dec->pass.size() > 1 || dec->pass[0].comp >= 0) {
+		// scans of single components: blocks no scan reaches stay zero (common.c:129)
+		if (hipMemsetAsync(dec->d_coefs, 0, (size_t)dec->nframes * dec->g.nblk * 64 * sizeof(int16_t), s) != hipSuccess) {
+			return RET_FAILURE_LOGIC_ERROR;
+		}
 	}
-	if (jh_launch_huff_decode(w, dec->g, s, &th)) {
-		return RET_FAILURE_LOGIC_ERROR;
+	for (DecPass &ps : dec->pass) {
+		hipLaunchKernelGGL(k_dec_init, dim3((dec->nframes + 63) / 64), dim3(64), 0, s, ps.d_state, dec->nframes);
+		if (jh_launch_ecs_unstuff(ps.work, s, &th)) {
+			return RET_FAILURE_LOGIC_ERROR;
+		}
+		if (jh_launch_huff_decode(ps.work, ps.g, s, &th)) {
+			return RET_FAILURE_LOGIC_ERROR;
+		}
 	}
 	dec->timer.begin("k_decode_pixels", s);
 	if (jh_launch_decode_pixels(dec->g, dec->nframes, dec->d_coefs, dec->d_quant, dec->last_out, dec->last_stride, s)) {
@@ -474,7 +616,7 @@ static int decoder_launch(jpeg_hip_decoder *dec, hipStream_t s)
 
 extern "C" int jpeg_hip_decoder_run(jpeg_hip_decoder *dec, void *d_samples, size_t frame_stride, void *stream)
 {
-	if (!dec || dec->nframes == 0 || !d_samples) {
+	if (!dec || dec->nframes == 0 || dec->pass.empty() || !d_samples) {
 		return RET_FAILURE_LOGIC_ERROR;
 	}
 	if (frame_stride < jpeg_hip_decoder_frame_bytes(dec)) {
@@ -497,20 +639,23 @@ extern "C" int jpeg_hip_decoder_sync(jpeg_hip_decoder *dec, int *frame_status)
 	}
 	HIPCHK(hipSetDevice(dec->device));
 	HIPCHK(hipStreamSynchronize(dec->last_stream));
-	HIPCHK(hipMemcpy(dec->state.data(), dec->d_state, dec->nframes * sizeof(JhDecState), hipMemcpyDeviceToHost));
+	for (DecPass &ps : dec->pass) {
+		HIPCHK(hipMemcpy(ps.state.data(), ps.d_state, dec->nframes * sizeof(JhDecState), hipMemcpyDeviceToHost));
+	}
 	int worst = RET_SUCCESS;
 	for (int f = 0; f < dec->nframes; ++f) {
 		int st = dec->parse_err[f];
-		if (!st) {
-			const JhDecState &ds = dec->state[f];
-			const JhDecFrame &fr = dec->frames[f];
-			dec->ecs_len[f] = ds.term_pos - fr.raw_begin;
+		dec->ecs_len[f] = 0;
+		for (size_t pi = 0; pi < dec->pass.size() && !st; ++pi) {
+			const JhDecState &ds = dec->pass[pi].state[f];
+			const JhDecFrame &fr = dec->pass[pi].frames[f];
+			dec->ecs_len[f] += ds.term_pos - fr.raw_begin;
 			if (ds.status & JH_ST_SEG_OVERFLOW) {
 				st = RET_FAILURE_FILE_UNSUPPORTED;
 			} else if (ds.term_pos >= fr.raw_end) {
 				st = RET_FAILURE_FILE_IO;            // no EOI: read_marker() hits end of file (io.c:197)
-			} else if (ds.term_marker != 0xd9) {
-				st = RET_FAILURE_FILE_UNSUPPORTED;   // further scans / tables after this ECS: not on the GPU path
+			} else if (pi + 1 == dec->pass.size() && dec->pass[pi].comp < 0 && ds.term_marker != 0xd9) {
+				st = RET_FAILURE_FILE_UNSUPPORTED;   // a scan of all components followed by more than EOI: not on the GPU path
 			}
 		}
 		if (frame_status) {
@@ -549,18 +694,23 @@ extern "C" int jpeg_hip_decoder_get_stats(const jpeg_hip_decoder *dec, int frame
 	if (!dec || !dec->ran || frame < 0 || frame >= dec->nframes) {
 		return RET_FAILURE_LOGIC_ERROR;
 	}
-	const JhDecState &s = dec->state[frame];
-	stats[0] = (s.status & JH_ST_SERIAL) ? (s.serial_cause ? s.serial_cause : 1u) : 0u;
-	stats[1] = s.nrepaired;
-	stats[2] = s.nblocks;
-	stats[3] = s.nseg;
+	stats[0] = stats[1] = stats[2] = stats[3] = 0;
+	for (const DecPass &ps : dec->pass) {                  // summed over the scans of the frame
+		const JhDecState &s = ps.state[frame];
+		stats[0] |= (s.status & JH_ST_SERIAL) ? (s.serial_cause ? s.serial_cause : 1u) : 0u;
+		stats[1] += s.nrepaired;
+		stats[2] += s.nblocks;
+		stats[3] += s.nseg;
+	}
 	return RET_SUCCESS;
 }
 
 extern "C" void jpeg_hip_decoder_set_debug(jpeg_hip_decoder *dec, int flags)
 {
 	dec->debug = flags;
-	dec->work.debug = flags;
+	for (DecPass &ps : dec->pass) {
+		ps.work.debug = flags;
+	}
 }
 
 extern "C" int jpeg_hip_decoder_ecs_bytes(const jpeg_hip_decoder *dec, size_t *ecs_len)

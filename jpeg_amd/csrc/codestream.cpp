@@ -455,21 +455,14 @@ int jh_split_stream(const uint8_t *p, size_t n, size_t *off, size_t *len, int ca
 	return count;
 }
 
-int jh_parse_headers(const uint8_t *p, size_t n, JhHeader *h)
+// parse_format (decoder.c:472-659) from r.pos up to and including the next SOS header.  eoi != NULL: an EOI
+// ends the walk with *eoi = true (the caller is between scans); eoi == NULL: an EOI before the first scan
+// is an error.
+static int parse_segments(Reader &r, JhHeader *h, bool *eoi)
 {
-	Reader r = {p, n, 0};
-	memset(h, 0, sizeof *h);
-	for (int t = 0; t < 4; ++t) {
-		for (int i = 0; i < 64; ++i) {
-			h->Q[t][i] = 1;                                    // common.c:10-21
-		}
-	}
-	for (int tc = 0; tc < 2; ++tc) {
-		for (int th = 0; th < 2; ++th) {
-			jh_default_table(tc, th, &h->ht[tc][th]);          // common.c:90-94
-		}
-	}
-	bool have_sof = false;
+	const uint8_t *p = r.p;
+	const size_t n = r.n;
+	bool &have_sof = h->have_sof;
 
 	for (;;) {
 		unsigned m;
@@ -642,10 +635,59 @@ int jh_parse_headers(const uint8_t *p, size_t n, JhHeader *h)
 			return RET_SUCCESS;
 		}
 		if (m == 0xffd9) {
+			if (eoi) {
+				*eoi = true;
+				return RET_SUCCESS;
+			}
 			return RET_FAILURE_FILE_UNSUPPORTED;               // EOI before any scan: nothing to decode here
 		}
 		return RET_FAILURE_FILE_UNSUPPORTED;                   // decoder.c:654-656
 	}
+}
+
+int jh_parse_headers(const uint8_t *p, size_t n, JhHeader *h)
+{
+	Reader r = {p, n, 0};
+	memset(h, 0, sizeof *h);
+	for (int t = 0; t < 4; ++t) {
+		for (int i = 0; i < 64; ++i) {
+			h->Q[t][i] = 1;                                    // common.c:10-21
+		}
+	}
+	for (int tc = 0; tc < 2; ++tc) {
+		for (int th = 0; th < 2; ++th) {
+			jh_default_table(tc, th, &h->ht[tc][th]);          // common.c:90-94
+		}
+	}
+	return parse_segments(r, h, nullptr);
+}
+
+int jh_parse_next_scan(const uint8_t *p, size_t n, size_t pos, JhHeader *h, bool *eoi)
+{
+	Reader r = {p, n, pos};
+	*eoi = false;
+	return parse_segments(r, h, eoi);
+}
+
+// read_ecs_byte (io.c:247-274): the entropy-coded data ends at the first FF xx with xx not in {00, D0..D7}
+size_t jh_ecs_end(const uint8_t *p, size_t n, size_t pos)
+{
+	while (pos < n) {
+		const uint8_t *q = (const uint8_t *)memchr(p + pos, 0xff, n - pos);
+		if (!q) {
+			return n;
+		}
+		pos = (size_t)(q - p);
+		if (pos + 1 >= n) {
+			return n;
+		}
+		const unsigned x = p[pos + 1];
+		if (x != 0x00 && !(x >= 0xd0 && x <= 0xd7)) {
+			return pos;
+		}
+		pos += 2;
+	}
+	return n;
 }
 
 // ---- header producer ---------------------------------------------------------------------------------

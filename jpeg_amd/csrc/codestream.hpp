@@ -20,10 +20,16 @@ struct JhHeader {
 	int Ns;
 	int scan_comp[JH_MAX_COMP];       // index into g.* of each scan component
 	size_t ecs_offset;                // first byte after the SOS header
+	bool have_sof;
 };
 
 // Parse SOI .. SOS of one codestream held in memory (decoder.c:472-659 restated).  Returns a RET_* code.
 int jh_parse_headers(const uint8_t *p, size_t n, JhHeader *h);
+
+// Files with several scans (non-interleaved components, decoder.c:593-633): continue behind the entropy-coded
+// data of a scan.  Tables may be redefined on the way; *eoi = true when EOI came instead of another SOS.
+int jh_parse_next_scan(const uint8_t *p, size_t n, size_t pos, JhHeader *h, bool *eoi);
+size_t jh_ecs_end(const uint8_t *p, size_t n, size_t pos);            // position of the marker that ends the ECS, or n
 
 // Geometry from P/X/Y/components (common.c:156-195, frame.c:16-35).  interleaved = scan holds all
 // components; a single-component frame is normalised to H = V = 1 over its padded block grid

@@ -315,6 +315,18 @@ __device__ __forceinline__ WrEntry load_entry(const JhDecodeWork &w, const JhDec
 	return e;
 }
 
+// block number in the scan's order -> block number in the coefficient buffer (JhRemap)
+__device__ __forceinline__ int remap_block(const JhRemap &rm, int n)
+{
+	if (!rm.mode) {
+		return n;
+	}
+	// raster position of the component -> (MCU, block of the MCU) of the frame
+	const int by = n / rm.bxc, bx = n - by * rm.bxc;
+	const int my = by / rm.V, mx = bx / rm.H;
+	return (my * rm.m_x + mx) * rm.B + rm.kfirst + (by - my * rm.V) * rm.H + (bx - mx * rm.H);
+}
+
 // The wave writes the blocks its lanes completed in this iteration.  fin: this lane completed a block;
 // fblk: its index in the frame, or -1 = discard (not this lane's block).  bufs = the workgroup's block
 // buffers as 16-byte chunks, buffer of thread i = chunks [8 i, 8 i + 8), logical chunk j of thread i at
@@ -382,7 +394,8 @@ __global__ __launch_bounds__(WR_THREADS) void k_huff_write(const HuffArgs a)
 	const uint32_t *seg_start = w.seg_start + fr.seg_off;
 	const uint32_t nseg = min(fs.nseg, fr.seg_cap - 1);
 	const int B = a.g.B, nblk = a.g.nblk;
-	int4 *frame_coefs = reinterpret_cast<int4 *>(w.coefs + (size_t)f * nblk * 64);
+	const JhRemap rm = w.rm;
+	int4 *frame_coefs = reinterpret_cast<int4 *>(w.coefs + (size_t)f * (rm.mode ? rm.nblk_full : nblk) * 64);
 	int16_t *mybuf = reinterpret_cast<int16_t *>(bufs + tid * 8);
 	int *dcs = &dcs_all[0][tid];
 
@@ -505,7 +518,14 @@ __global__ __launch_bounds__(WR_THREADS) void k_huff_write(const HuffArgs a)
 				const uint32_t npos = pos + (uint32_t)total;
 				if (e1 == 0 || npos > seg_end) {
 					// end of this restart segment (decoder.c:376-381): the MCU in progress is dropped, the
-					// next segment starts with block 0 / DC predictors 0 (decoder.c:369-373)
+					// next segment starts with block 0 / DC predictors 0 (decoder.c:369-373).
+					// The blocks of the dropped MCU were stored when they were completed, possibly by other
+					// threads, and the next segment's blocks go to the same places: k_huff_fixup settles
+					// the order afterwards.  Recorded by the thread in whose sub-sequence the segment ends.
+					if (c != 0 && pos < stop && seg + 1 < nseg) {
+						w.drop[fr.seg_off + seg + 1] = ((unsigned long long)(uint32_t)(blk - c) << 8) | (unsigned)c;
+						atomicAdd(&w.state[f].ndrop, 1u);
+					}
 					blk -= c;
 					c = 0;
 					z = 0;
@@ -546,6 +566,9 @@ __global__ __launch_bounds__(WR_THREADS) void k_huff_write(const HuffArgs a)
 				if (done) {
 					fin = true;
 					fblk = (own && blk >= 0 && blk < nblk && blk < limit_blk) ? blk : -1;
+					if (rm.mode && fblk >= 0) {
+						fblk = remap_block(rm, fblk);
+					}
 					own = true;
 					blk++;
 				}
@@ -569,6 +592,114 @@ __global__ __launch_bounds__(256) void k_coef_tail_clear(const HuffArgs a)
 	}
 }
 
+// A restart segment that ends inside an MCU (truncated data, or an interval that is no multiple of the
+// reference's block group in a single-component scan): the reference does not count that MCU
+// (decoder.c:376-381), so the next segment's first blocks land where its blocks were stored.  In
+// k_huff_write both are stored by unrelated threads; here the later ones are decoded once more, in
+// segment order, after everything else.  One wave per frame, lane 0 decodes: such streams are rare,
+// a frame without them costs one load.
+__device__ void fixup_segment(const HuffArgs &a, const JhDecFrame *fr, int16_t *fc, const GlobalStream &G,
+                              const unsigned char *luts, uint32_t pos, const uint32_t seg_end, int first, int count)
+{
+	const JhRemap rm = a.w.rm;
+	int pred[JH_MAX_COMP];
+#pragma unroll
+	for (int q = 0; q < JH_MAX_COMP; ++q) {
+		pred[q] = 0;
+	}
+	for (int c = 0; c < count; ++c) {
+		const int n = first + c;
+		const unsigned char *tdc = luts + (size_t)fr->blk_dc[c] * sizeof(JhHuffLut);
+		const unsigned char *tac = luts + (size_t)fr->blk_ac[c] * sizeof(JhHuffLut);
+		const int comp = a.g.blk_comp[c];
+		int16_t *dst = n < a.g.nblk ? fc + (size_t)remap_block(rm, n) * 64 : nullptr;
+		int dcv = 0;
+		uint32_t end_pos = pos;
+		// pass 0 proves that the block is complete inside the segment, pass 1 stores it
+		for (int pass = 0; pass < 2; ++pass) {
+			if (pass == 1 && dst) {
+				for (int j = 0; j < 8; ++j) {
+					reinterpret_cast<int4 *>(dst)[j] = make_int4(0, 0, 0, 0);
+				}
+			}
+			uint32_t p = pos;
+			int z = 0;
+			for (;;) {
+				const bool isdc = z == 0;
+				const unsigned char *tab = isdc ? tdc : tac;
+				const uint32_t wj = p >> 5;
+				const uint32_t wn = bit_window(G.word(wj), G.word(wj + 1), p);
+				unsigned e = reinterpret_cast<const uint16_t *>(tab)[wn >> (32 - JH_LUT_BITS)];
+				if (e & 0x8000u) {
+					e = long_code(tab, e, wn, isdc);
+				}
+				const int total = (int)(e >> 10), run = (int)((e >> 4) & 63u), cat = (int)(e & 15u);
+				if (e == 0 || p + (uint32_t)total > seg_end) {
+					return;                            // the segment ends inside this block: what is there stays
+				}
+				int val = extend_sign(__builtin_amdgcn_ubfe(wn, 32u - (unsigned)total, (unsigned)cat), cat);
+				if (isdc) {
+#pragma unroll
+					for (int q = 0; q < JH_MAX_COMP; ++q) {
+						val += q == comp ? pred[q] : 0;
+					}
+					dcv = val;
+				}
+				const int k = z + run;
+				if (pass == 1 && dst && k < 64 && (isdc || cat != 0)) {
+					dst[k] = (int16_t)val;
+				}
+				p += (uint32_t)total;
+				z = k + 1;
+				if (k >= 63) {
+					break;
+				}
+			}
+			end_pos = p;
+		}
+#pragma unroll
+		for (int q = 0; q < JH_MAX_COMP; ++q) {
+			pred[q] = q == comp ? dcv : pred[q];
+		}
+		pos = end_pos;
+	}
+}
+
+__global__ __launch_bounds__(64) void k_huff_fixup(const HuffArgs a)
+{
+	const JhDecodeWork &w = a.w;
+	const int f = blockIdx.x;
+	const JhDecState fs = w.state[f];
+	if (fs.ndrop == 0) {
+		return;
+	}
+	const JhDecFrame *fr = w.frames + f;
+	const uint32_t nseg = min(fs.nseg, fr->seg_cap - 1);
+	const uint32_t total_bits = fs.cs_len * 8u;
+	const uint32_t *seg_start = w.seg_start + fr->seg_off;
+	const unsigned long long *drop = w.drop + fr->seg_off;
+	const unsigned char *luts = reinterpret_cast<const unsigned char *>(w.luts + fr->lut_off);
+	const GlobalStream G{w.cs + fr->cs_off};
+	int16_t *fc = w.coefs + (size_t)f * (w.rm.mode ? w.rm.nblk_full : a.g.nblk) * 64;
+	const int lane = threadIdx.x;
+	for (uint32_t s0 = 0; s0 < nseg; s0 += 64) {
+		const uint32_t s = s0 + lane;
+		const unsigned long long ev = s < nseg ? drop[s] : 0ull;
+		unsigned long long m = __ballot(ev != 0);
+		while (m) {
+			const int src = __builtin_ctzll(m);
+			m &= m - 1;
+			const uint32_t lo = __shfl((uint32_t)ev, src, 64), hi = __shfl((uint32_t)(ev >> 32), src, 64);
+			if (lane == 0) {
+				const unsigned long long e = ((unsigned long long)hi << 32) | lo;
+				const uint32_t sg = s0 + (uint32_t)src;
+				fixup_segment(a, fr, fc, G, luts, seg_start[sg] * 8u, min(seg_start[sg + 1] * 8u, total_bits),
+				              (int)(e >> 8), (int)(e & 0xffu));
+			}
+		}
+	}
+}
+
 int jh_launch_huff_decode(const JhDecodeWork &w, const JhGeom &g, hipStream_t s, const JhTimerHook *th)
 {
 	HuffArgs a;
@@ -588,8 +719,13 @@ int jh_launch_huff_decode(const JhDecodeWork &w, const JhGeom &g, hipStream_t s,
 	JH_T_BEGIN(th, "k_huff_write", s);
 	hipLaunchKernelGGL(k_huff_write, gsub, dim3(WR_THREADS), lds, s, a);
 	JH_T_END(th, s);
-	JH_T_BEGIN(th, "k_coef_tail_clear", s);
-	hipLaunchKernelGGL(k_coef_tail_clear, dim3(64, w.nframes), dim3(256), 0, s, a);
+	JH_T_BEGIN(th, "k_huff_fixup", s);
+	hipLaunchKernelGGL(k_huff_fixup, dim3(w.nframes), dim3(64), 0, s, a);
 	JH_T_END(th, s);
+	if (w.rm.mode == 0) {                              // scans of single components: the caller cleared the buffer
+		JH_T_BEGIN(th, "k_coef_tail_clear", s);
+		hipLaunchKernelGGL(k_coef_tail_clear, dim3(64, w.nframes), dim3(256), 0, s, a);
+		JH_T_END(th, s);
+	}
 	return hipGetLastError() == hipSuccess ? 0 : -1;
 }

@@ -47,6 +47,20 @@ struct JhDecState {               // written by the device
 	uint32_t serial_cause;        // why the serial walk was asked for: 2 entry states still
 	                              // inconsistent after the walk rounds, 4 a walk had to decode too much by itself, 16 test hook
 	uint32_t term_marker;         // second byte of the marker at term_pos (0xd9 = EOI)
+	uint32_t ndrop;               // restart segments that ended inside an MCU (k_huff_fixup has work)
+};
+
+// A scan that codes ONE component of a multi-component frame (non-interleaved order, decoder.c:274-302)
+// walks that component's blocks as a raster over its padded grid; the coefficient buffer keeps the
+// interleaved order the pixel kernel reads, so the write pass translates block numbers.
+struct JhRemap {
+	int mode;                     // 0: the scan order IS the buffer order; 1: raster of one component
+	int bxc;                      // blocks per row of the component (b_x)
+	int H, V;                     // its sampling factors
+	int m_x;                      // MCUs per row of the frame
+	int B;                        // blocks per MCU of the frame (buffer order)
+	int kfirst;                   // first block of the component inside an MCU
+	int nblk_full;                // blocks per frame in the buffer
 };
 
 struct JhDecodeWork {             // device pointers of one decoder batch
@@ -61,6 +75,7 @@ struct JhDecodeWork {             // device pointers of one decoder batch
 	JhWgAgg *wg_agg;              // per chains workgroup: totals of its emitted range, flags
 	JhWgAgg *wg_base;             // per chains workgroup: exclusive prefix of the totals
 	JhSubStart *start;            // entry records for the write pass (relative to the workgroup's base)
+	unsigned long long *drop;     // per restart segment: (first block << 8) | blocks of the MCU the PREVIOUS segment left unfinished
 	const JhDecFrame *frames;
 	JhDecState *state;
 	const JhHuffLut *luts;
@@ -70,6 +85,7 @@ struct JhDecodeWork {             // device pointers of one decoder batch
 	uint32_t max_subs;            // per frame (grid size)
 	uint32_t max_luts;            // Huffman tables of the frame that uses most (LDS size)
 	int debug;                    // bit 0: force repairs, bit 1: force the serial walk (tests)
+	JhRemap rm;
 };
 
 int jh_launch_ecs_unstuff(const JhDecodeWork &w, hipStream_t s, const JhTimerHook *th);

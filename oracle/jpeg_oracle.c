@@ -1526,6 +1526,167 @@ out:
 	return err;
 }
 
+/*
+ * EXTENSION (test input generator; the reference encoder writes one interleaved scan only):
+ * the image of orc_encode() coded as ONE SCAN PER COMPONENT (A.2.2 non-interleaved order), which the
+ * reference DEcoder reads through its Ns == 1 walk (decoder.c:274-302): the blocks of a component in
+ * raster order over its padded grid b_x x b_y (quirk Q8), DC prediction along that order, predictors
+ * back to 0 at the start of every scan.  restart_interval counts blocks here (an MCU of such a scan is
+ * one block).  redefine != 0: every scan names table ids 0/0 and a DHT in front of each scan redefines
+ * them (tables "as they stand when the scan starts", decoder.c:581-591).
+ * The judge of these streams is the reference decoder (tests/golden/make_golden.py).
+ */
+int orc_encode_scans(const uint8_t *body, int X, int Y, int Nf, int P, int H, int V, int q,
+                     int optimize, int restart_interval, int redefine,
+                     uint8_t **jpg, size_t *jpg_len)
+{
+	orc_image *img = NULL;
+	uint8_t *first = NULL;
+	size_t first_len = 0;
+	sink s = {0};
+	hufftab *dc = NULL, *ac = NULL;
+
+	*jpg = NULL;
+	*jpg_len = 0;
+	int err = orc_encode(body, X, Y, Nf, P, H, V, q, optimize, 0, &img, &first, &first_len);
+	if (err) {
+		return err;
+	}
+	free(first);
+	dc = calloc(1, sizeof *dc);
+	ac = calloc(1, sizeof *ac);
+	if (dc == NULL || ac == NULL) {
+		err = ORC_ERR_MEMORY;
+		goto out;
+	}
+	if (optimize) {
+		/* the DC differences follow the order of THIS walk: statistics and tables again (Annex K.2) */
+		size_t (*freq)[4][257] = calloc(2, sizeof(size_t[4][257]));
+		if (freq == NULL) {
+			err = ORC_ERR_MEMORY;
+			goto out;
+		}
+		for (int tc = 0; tc < 2; ++tc) {
+			for (int th = 0; th < 4; ++th) {
+				freq[tc][th][256] = 1;
+			}
+		}
+		for (int k = 0; k < img->ncomp; ++k) {
+			orc_comp *c = &img->comp[k];
+			int32_t pred = 0;
+			for (size_t b = 0; b < c->bx * c->by; ++b) {
+				if (restart_interval > 0 && b > 0 && b % (size_t)restart_interval == 0) {
+					pred = 0;
+				}
+				int32_t blk[64];
+				memcpy(blk, &c->coef[b * 64], sizeof blk);
+				int32_t dcv = blk[0];
+				blk[0] -= pred;
+				pred = dcv;
+				code_block(NULL, NULL, NULL, freq[0][c->Td], freq[1][c->Ta], blk);
+			}
+		}
+		for (int tc = 0; tc < 2; ++tc) {
+			for (int th = 0; th < (Nf > 1 ? 2 : 1); ++th) {
+				orc_adapt_table(freq[tc][th], img->htL[tc][th], img->htV[tc][th]);
+			}
+		}
+		free(freq);
+	}
+	sink_marker(&s, 0xd8);
+	for (int t = 0; t < (Nf > 1 ? 2 : 1); ++t) {
+		sink_marker(&s, 0xdb);
+		sink_word(&s, 67);
+		sink_put(&s, (uint8_t)t);
+		for (int i = 0; i < 64; ++i) {
+			sink_put(&s, (uint8_t)img->Q[t][zz[i]]);
+		}
+	}
+	sink_marker(&s, 0xc0);
+	sink_word(&s, 8u + 3u * (unsigned)Nf);
+	sink_put(&s, (uint8_t)P);
+	sink_word(&s, (unsigned)Y);
+	sink_word(&s, (unsigned)X);
+	sink_put(&s, (uint8_t)Nf);
+	for (int k = 0; k < img->ncomp; ++k) {
+		sink_put(&s, (uint8_t)img->comp[k].id);
+		sink_put(&s, (uint8_t)((img->comp[k].H << 4) | img->comp[k].V));
+		sink_put(&s, (uint8_t)img->comp[k].Tq);
+	}
+	if (!redefine) {
+		for (int th = 0; th < (Nf > 1 ? 2 : 1); ++th) {
+			put_dht(&s, 0, th, img->htL[0][th], img->htV[0][th]);
+			put_dht(&s, 1, th, img->htL[1][th], img->htV[1][th]);
+		}
+	}
+	if (restart_interval > 0) {
+		sink_marker(&s, 0xdd);
+		sink_word(&s, 4);
+		sink_word(&s, (unsigned)restart_interval);
+	}
+	for (int k = 0; k < img->ncomp; ++k) {
+		orc_comp *c = &img->comp[k];
+		int td = c->Td, ta = c->Ta;
+		hufftab_build(dc, img->htL[0][td], img->htV[0][td]);
+		orc_make_codes(img->htL[0][td], img->htV[0][td], dc->ehufsi, dc->ehufco);
+		hufftab_build(ac, img->htL[1][ta], img->htV[1][ta]);
+		orc_make_codes(img->htL[1][ta], img->htV[1][ta], ac->ehufsi, ac->ehufco);
+		if (redefine) {
+			put_dht(&s, 0, 0, img->htL[0][td], img->htV[0][td]);
+			put_dht(&s, 1, 0, img->htL[1][ta], img->htV[1][ta]);
+			td = ta = 0;
+		}
+		sink_marker(&s, 0xda);
+		sink_word(&s, 8);
+		sink_put(&s, 1);
+		sink_put(&s, (uint8_t)c->id);
+		sink_put(&s, (uint8_t)((td << 4) | ta));
+		sink_put(&s, 0);
+		sink_put(&s, 63);
+		sink_put(&s, 0);
+		bitw w = {&s, 0, 0};
+		int32_t pred = 0;
+		unsigned rst = 0;
+		size_t total = c->bx * c->by;
+		for (size_t b = 0; b < total; ++b) {
+			if (restart_interval > 0 && b > 0 && b % (size_t)restart_interval == 0) {
+				bitw_flush(&w);
+				sink_marker(&s, 0xd0 + (rst & 7));
+				rst++;
+				pred = 0;
+			}
+			int32_t blk[64];
+			memcpy(blk, &c->coef[b * 64], sizeof blk);
+			int32_t dcv = blk[0];
+			blk[0] -= pred;
+			pred = dcv;
+			if (blk[0] < -2047 || blk[0] > 2047) {
+				err = ORC_ERR_DC_RANGE;
+				goto out;
+			}
+			err = code_block(&w, dc, ac, NULL, NULL, blk);
+			if (err) {
+				goto out;
+			}
+		}
+		bitw_flush(&w);
+	}
+	sink_marker(&s, 0xd9);
+	if (s.oom) {
+		err = ORC_ERR_MEMORY;
+		goto out;
+	}
+	*jpg = s.p;
+	*jpg_len = s.n;
+	s.p = NULL;
+out:
+	free(s.p);
+	free(dc);
+	free(ac);
+	orc_image_free(img);
+	return err;
+}
+
 /* ======================================================================== accessors */
 
 void orc_img_info(const orc_image *img, int *P, int *X, int *Y, int *Nf, int *ncomp,

@@ -120,6 +120,21 @@ def main():
     # trailing garbage after EOI and a second frame appended: only frame 0 is decoded
     dec_inputs["d_two_frames"] = jpg + jpg[:200]
 
+    # one scan per component (non-interleaved order, decoder.c:274-302): written by the oracle's extension
+    # writer, judged by the reference decoder like every other input here
+    for name, (X, Y, H, V, q, opt, ri, redef, seed) in {
+        "d_scans_420_opt": (80, 64, 2, 2, 80, 1, 0, 0, 51),
+        "d_scans_444_rst7": (64, 48, 1, 1, 90, 0, 7, 0, 52),
+        "d_scans_422_redefine": (96, 40, 2, 1, 70, 1, 0, 1, 53),
+        "d_scans_420_unaligned_rst8": (100, 75, 2, 2, 80, 1, 8, 1, 54),
+        # an interval that ends inside the reference's H x V block group: bug-compatible, not standard
+        "d_scans_420_rst5_quirk": (100, 75, 2, 2, 80, 1, 5, 0, 55),
+    }.items():
+        err, data = orc.encode_scans(synth_image(X, Y, 3, 8, seed, False), P=8, H=H, V=V, q=q, optimize=opt,
+                                     restart_interval=ri, redefine=redef)
+        assert err == 0, (name, err)
+        dec_inputs[name] = data
+
     try:
         from PIL import Image
         rgb = synth_image(112, 80, 3, 8, 41, False)

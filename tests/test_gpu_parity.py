@@ -245,6 +245,46 @@ def test_garbage_in_the_entropy_coded_data(hip, oracle):
         assert np.array_equal(outs[0][:rows], opx[:rows])
 
 
+def _cut_intervals(jpg, which, keep=0.55):
+    """Drop the tail of the restart intervals listed in `which` (their data then ends inside an MCU)."""
+    sos = jpg.index(b"\xff\xda")
+    start = sos + 2 + ((jpg[sos + 2] << 8) | jpg[sos + 3])
+    marks = [i for i in range(start, len(jpg) - 1) if jpg[i] == 0xFF and 0xD0 <= jpg[i + 1] <= 0xD7]
+    bounds = [start] + [m + 2 for m in marks]          # first data byte of every interval
+    ends = marks + [len(jpg) - 2]                      # the marker (or EOI) behind it
+    out = bytearray(jpg[:start])
+    for k, (b, e) in enumerate(zip(bounds, ends)):
+        n = e - b
+        if k in which:
+            n = max(2, int(n * keep))
+            while jpg[b + n - 1] == 0xFF:              # never end on the first half of FF 00
+                n -= 1
+        out += jpg[b:b + n] + jpg[e:e + 2]
+    return bytes(out)
+
+
+@pytest.mark.parametrize("sync_debug", [0, 2])
+def test_intervals_that_end_inside_an_mcu(hip, oracle, sync_debug):
+    """Truncated restart intervals: the reference does not count the unfinished MCU (decoder.c:376-381),
+    so the next interval's blocks go where its blocks were stored.  On the GPU both are stored by
+    unrelated threads; k_huff_fixup settles the order.  Cut intervals whose successor is complete give
+    exactly the reference's coefficients and samples."""
+    img = synth_image(256, 192, 3, 8, seed=77)
+    err, jpg, _ = oracle.encode(img, P=8, H=2, V=2, q=85, optimize=1, restart_interval=3)
+    assert err == 0
+    bad = _cut_intervals(jpg, {1, 4, 5 + 2, 20, 41, 42 + 9})
+    err, opx, oinfo = oracle.decode(bad)
+    assert err == 0
+    d = hip.Decoder()
+    d.prepare([bad])
+    d.set_debug(sync_debug)
+    out = d.run()
+    assert d.sync() == [0]
+    _assert_coefs(d.coefficients(0), oinfo)
+    assert np.array_equal(d.to_arrays(out)[0], opx)
+    d.close()
+
+
 def test_motion_jpeg_stream_in_batches(hip, oracle):
     """A concatenated stream (incl. DHT-less frames that rely on the implicit tables, common.c:90-99)
     is split by the C++ splitter and decoded in batches; every frame equals the oracle's decode."""
