@@ -230,6 +230,24 @@ def main():
                                       "encode_frames_per_s": round(world * Fm * args.steps / te, 1),
                                       "frames_per_gpu_per_step": Fm, "bytes_per_frame": len(jpgs2[0])}
 
+        if rank == 0 and world == 1:
+            # host-inclusive (NOT `value`): codestreams in pageable host memory -> samples in HBM, with the
+            # double-buffered stream helper; PCIe H2D, header parsing and Huffman table set-up included
+            from jpeg_amd import mjpeg
+            enc2.close()
+            dec2.close()
+            del out2, samples2
+            nb = 16
+            for _ in range(2):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                n = 0
+                for o, st in mjpeg.decode_stream(jpgs2 * nb, batch=Fm):
+                    n += o.shape[0]
+                torch.cuda.synchronize()
+                th = time.perf_counter() - t0
+            res["mjpeg_1080p_422_q85"]["host_inclusive_decode_frames_per_s"] = round(n / th, 1)
+
     if rank == 0 and world == 1 and not args.no_cpu:
         res["cpu_baseline"] = cpu_baseline(imgs, jpgs, cfg)
     if rank == 0:

@@ -9,6 +9,10 @@
 #include <string.h>
 #include <ctype.h>
 #include <vector>
+#include <map>
+#include <thread>
+#include <utility>
+#include <chrono>
 #include <string>
 #include "../../include/jpeg_amd.h"
 #include "common.hpp"
@@ -191,6 +195,8 @@ struct jpeg_hip_decoder {
 	std::vector<size_t> ecs_len;
 	// device
 	uint8_t *d_raw = nullptr;
+	uint8_t *h_stage = nullptr;       // pinned staging for the codestreams, kept between prepare() calls
+	size_t stage_bytes = 0;
 	JhQuant *d_quant = nullptr;
 	int16_t *d_coefs = nullptr;
 	size_t raw_bytes = 0;
@@ -201,6 +207,27 @@ struct jpeg_hip_decoder {
 	int debug = 0;
 	StageTimer timer;
 
+	// Device buffers only grow: a decoder that is prepared again with a batch of similar size (Motion
+	// JPEG) allocates nothing, and hipMalloc / hipFree would wait for every stream of the device.
+	std::map<void **, size_t> cap;    // keyed by the address of the pointer member (pass never relocates)
+	hipError_t grow(void **p, size_t bytes)
+	{
+		size_t &c = cap[p];
+		if (*p && c >= bytes) {
+			return hipSuccess;
+		}
+		if (*p) {
+			hipFree(*p);
+			*p = nullptr;
+			c = 0;
+		}
+		const size_t want = bytes + bytes / 4 + 256;
+		hipError_t e = hipMalloc(p, want);
+		if (e == hipSuccess) {
+			c = want;
+		}
+		return e;
+	}
 	void release()
 	{
 		for (DecPass &p : pass) {
@@ -209,6 +236,7 @@ struct jpeg_hip_decoder {
 		pass.clear();
 		hipFree(d_raw); hipFree(d_quant); hipFree(d_coefs);
 		d_raw = nullptr; d_quant = nullptr; d_coefs = nullptr;
+		cap.clear();
 	}
 };
 
@@ -221,6 +249,7 @@ extern "C" int jpeg_hip_decoder_create(jpeg_hip_decoder **dec, int device)
 	}
 	jpeg_hip_decoder *d = new jpeg_hip_decoder();
 	d->device = device;
+	d->pass.reserve(JH_MAX_COMP);                          // addresses of the passes stay put (see cap)
 	memset(&d->g, 0, sizeof d->g);
 	*dec = d;
 	return RET_SUCCESS;
@@ -231,6 +260,9 @@ extern "C" void jpeg_hip_decoder_destroy(jpeg_hip_decoder *dec)
 	if (dec) {
 		hipSetDevice(dec->device);
 		dec->release();
+		if (dec->h_stage) {
+			hipHostFree(dec->h_stage);
+		}
 		delete dec;
 	}
 }
@@ -326,12 +358,22 @@ extern "C" int jpeg_hip_decoder_prepare(jpeg_hip_decoder *dec, int nframes,
 		return RET_FAILURE_LOGIC_ERROR;
 	}
 	HIPCHK(hipSetDevice(dec->device));
-	dec->release();
+	if (dec->ran) {
+		HIPCHK(hipStreamSynchronize(dec->last_stream));    // the buffers are about to be reused
+	}
 	dec->ran = false;
 	dec->nframes = nframes;
 	dec->parse_err.assign(nframes, 0);
 	dec->ecs_len.assign(nframes, 0);
 
+	auto T0 = std::chrono::steady_clock::now();
+	auto lap = [&](const char *what) {
+		if (getenv("JPEG_HIP_TRACE")) {
+			auto T1 = std::chrono::steady_clock::now();
+			fprintf(stderr, "[prepare] %-10s %.3f ms\n", what, std::chrono::duration<double, std::milli>(T1 - T0).count());
+			T0 = T1;
+		}
+	};
 	std::vector<JhHeader> hdr(nframes);
 	std::vector<std::vector<ScanDesc>> scans(nframes);
 	std::vector<JhQuant> quant(nframes);
@@ -378,6 +420,7 @@ extern "C" int jpeg_hip_decoder_prepare(jpeg_hip_decoder *dec, int nframes,
 			}
 		}
 	}
+	lap("parse");
 	if (!have_geom) {
 		// nothing decodable: report the first parse error
 		return dec->parse_err[0] ? dec->parse_err[0] : RET_FAILURE_FILE_UNSUPPORTED;
@@ -388,11 +431,21 @@ extern "C" int jpeg_hip_decoder_prepare(jpeg_hip_decoder *dec, int nframes,
 	dec->raw_bytes = raw_off + 4096;
 	const JhGeom &G = dec->g;
 
+	if (pass_comp.size() > (size_t)JH_MAX_COMP) {
+		return RET_FAILURE_FILE_UNSUPPORTED;
+	}
+	while (dec->pass.size() > pass_comp.size()) {
+		dec->pass.back().release();
+		dec->pass.pop_back();
+	}
 	dec->pass.resize(pass_comp.size());
 	for (size_t pi = 0; pi < pass_comp.size(); ++pi) {
 		DecPass &ps = dec->pass[pi];
 		ps.comp = pass_comp[pi];
 		ps.g = G;
+		ps.luts.clear();
+		ps.cs_off = ps.seg_off = ps.chunk_off = ps.sub_off = ps.wg_off = 0;
+		ps.max_chunks = ps.max_subs = ps.max_luts = 1;
 		JhRemap rm;
 		memset(&rm, 0, sizeof rm);
 		rm.nblk_full = G.nblk;
@@ -416,6 +469,8 @@ extern "C" int jpeg_hip_decoder_prepare(jpeg_hip_decoder *dec, int nframes,
 		}
 		ps.frames.assign(nframes, JhDecFrame());
 		ps.state.assign(nframes, JhDecState());
+		std::vector<std::pair<int, JhHuffSpec>> prev_specs;
+		uint32_t prev_lut_off = 0;
 		for (int f = 0; f < nframes; ++f) {
 			JhDecFrame &fr = ps.frames[f];
 			memset(&fr, 0, sizeof fr);
@@ -456,19 +511,42 @@ extern "C" int jpeg_hip_decoder_prepare(jpeg_hip_decoder *dec, int nframes,
 			fr.wg_off = (uint32_t)ps.wg_off;
 			ps.wg_off += fr.sub_cap / JH_SEQ_OWN + 2;
 			fr.nchunk = (uint32_t)((fr.raw_end + 4095) / 4096 - fr.raw_begin / 4096);
-			// Huffman tables used by this scan -> LDS slots
+			// Huffman tables used by this scan -> LDS slots.  Frames of a Motion JPEG stream mostly share
+			// their tables: a frame whose tables equal the previous frame's reuses its look-up tables.
 			int slot_of[2][4] = {{-1, -1, -1, -1}, {-1, -1, -1, -1}};
-			fr.lut_off = (uint32_t)ps.luts.size();
 			const int k0 = ps.comp >= 0 ? ps.comp : 0, k1 = ps.comp >= 0 ? ps.comp + 1 : G.ncomp;
-			for (int k = k0; k < k1 && !err; ++k) {
+			std::vector<std::pair<int, const JhHuffSpec *>> used;
+			for (int k = k0; k < k1; ++k) {
 				const int ids[2] = {sd.Td[k], sd.Ta[k]};
-				for (int tc = 0; tc < 2 && !err; ++tc) {
+				for (int tc = 0; tc < 2; ++tc) {
 					if (slot_of[tc][ids[tc]] < 0) {
-						JhHuffLut l;
-						err = jh_build_declut(&sd.ht[tc][ids[tc]], tc, &l);
-						slot_of[tc][ids[tc]] = (int)fr.n_lut++;
-						ps.luts.push_back(l);
+						slot_of[tc][ids[tc]] = (int)used.size();
+						used.push_back(std::make_pair(tc, &sd.ht[tc][ids[tc]]));
 					}
+				}
+			}
+			bool same_as_prev = prev_specs.size() == used.size();
+			for (size_t i = 0; same_as_prev && i < used.size(); ++i) {
+				same_as_prev = prev_specs[i].first == used[i].first &&
+				               memcmp(&prev_specs[i].second, used[i].second, sizeof(JhHuffSpec)) == 0;
+			}
+			if (same_as_prev) {
+				fr.lut_off = prev_lut_off;
+				fr.n_lut = (uint32_t)used.size();
+			} else {
+				fr.lut_off = (uint32_t)ps.luts.size();
+				for (size_t i = 0; i < used.size() && !err; ++i) {
+					JhHuffLut l;
+					err = jh_build_declut(used[i].second, used[i].first, &l);
+					fr.n_lut++;
+					ps.luts.push_back(l);
+				}
+				prev_specs.clear();
+				if (!err) {
+					for (size_t i = 0; i < used.size(); ++i) {
+						prev_specs.push_back(std::make_pair(used[i].first, *used[i].second));
+					}
+					prev_lut_off = fr.lut_off;
 				}
 			}
 			if (err) {
@@ -495,44 +573,83 @@ extern "C" int jpeg_hip_decoder_prepare(jpeg_hip_decoder *dec, int nframes,
 		if (ps.luts.empty()) {
 			ps.luts.push_back(JhHuffLut());
 		}
+		lap("luts");
 		const size_t cs_bytes = ps.cs_off + 64, seg_entries = ps.seg_off + 4, chunk_entries = ps.chunk_off + 4;
 		const size_t sub_entries = ps.sub_off + 4, wg_entries = ps.wg_off + 4;
-		HIPCHK(hipMalloc((void **)&ps.d_cs, cs_bytes));
-		HIPCHK(hipMalloc((void **)&ps.d_seg, seg_entries * 4));
-		HIPCHK(hipMalloc((void **)&ps.d_chunk_kept, chunk_entries * 4));
-		HIPCHK(hipMalloc((void **)&ps.d_chunk_rst, chunk_entries * 4));
-		HIPCHK(hipMalloc((void **)&ps.d_start, sub_entries * sizeof(JhSubStart)));
-		HIPCHK(hipMalloc((void **)&ps.d_rec, sub_entries * (JH_CHAIN_MAX + 1) * sizeof(JhSubInfo)));
-		HIPCHK(hipMalloc((void **)&ps.d_meta, sub_entries * sizeof(uint32_t)));
-		HIPCHK(hipMalloc((void **)&ps.d_prec, sub_entries * sizeof(JhSubInfo)));
-		HIPCHK(hipMalloc((void **)&ps.d_wg_key, wg_entries * sizeof(unsigned long long)));
-		HIPCHK(hipMalloc((void **)&ps.d_wg_agg, wg_entries * sizeof(JhWgAgg)));
-		HIPCHK(hipMalloc((void **)&ps.d_wg_base, wg_entries * sizeof(JhWgAgg)));
+		HIPCHK(dec->grow((void **)&ps.d_cs, cs_bytes));
+		HIPCHK(dec->grow((void **)&ps.d_seg, seg_entries * 4));
+		HIPCHK(dec->grow((void **)&ps.d_chunk_kept, chunk_entries * 4));
+		HIPCHK(dec->grow((void **)&ps.d_chunk_rst, chunk_entries * 4));
+		HIPCHK(dec->grow((void **)&ps.d_start, sub_entries * sizeof(JhSubStart)));
+		HIPCHK(dec->grow((void **)&ps.d_rec, sub_entries * (JH_CHAIN_MAX + 1) * sizeof(JhSubInfo)));
+		HIPCHK(dec->grow((void **)&ps.d_meta, sub_entries * sizeof(uint32_t)));
+		HIPCHK(dec->grow((void **)&ps.d_prec, sub_entries * sizeof(JhSubInfo)));
+		HIPCHK(dec->grow((void **)&ps.d_wg_key, wg_entries * sizeof(unsigned long long)));
+		HIPCHK(dec->grow((void **)&ps.d_wg_agg, wg_entries * sizeof(JhWgAgg)));
+		HIPCHK(dec->grow((void **)&ps.d_wg_base, wg_entries * sizeof(JhWgAgg)));
 		HIPCHK(hipMemset(ps.d_meta, 0, sub_entries * sizeof(uint32_t)));
 		HIPCHK(hipMemset(ps.d_wg_agg, 0, wg_entries * sizeof(JhWgAgg)));
 		HIPCHK(hipMemset(ps.d_wg_base, 0, wg_entries * sizeof(JhWgAgg)));
-		HIPCHK(hipMalloc((void **)&ps.d_frames, nframes * sizeof(JhDecFrame)));
-		HIPCHK(hipMalloc((void **)&ps.d_state, nframes * sizeof(JhDecState)));
-		HIPCHK(hipMalloc((void **)&ps.d_luts, ps.luts.size() * sizeof(JhHuffLut)));
+		HIPCHK(dec->grow((void **)&ps.d_frames, nframes * sizeof(JhDecFrame)));
+		HIPCHK(dec->grow((void **)&ps.d_state, nframes * sizeof(JhDecState)));
+		HIPCHK(dec->grow((void **)&ps.d_luts, ps.luts.size() * sizeof(JhHuffLut)));
 		HIPCHK(hipMemset(ps.d_cs, 0, cs_bytes));
 		HIPCHK(hipMemset(ps.d_seg, 0, seg_entries * 4));
-		HIPCHK(hipMalloc((void **)&ps.d_drop, seg_entries * sizeof(unsigned long long)));
+		HIPCHK(dec->grow((void **)&ps.d_drop, seg_entries * sizeof(unsigned long long)));
 		HIPCHK(hipMemset(ps.d_drop, 0, seg_entries * sizeof(unsigned long long)));
 		HIPCHK(hipMemcpy(ps.d_frames, ps.frames.data(), nframes * sizeof(JhDecFrame), hipMemcpyHostToDevice));
 		HIPCHK(hipMemcpy(ps.d_luts, ps.luts.data(), ps.luts.size() * sizeof(JhHuffLut), hipMemcpyHostToDevice));
 		ps.work.rm = rm;
+		lap("pass alloc");
 	}
 
-	HIPCHK(hipMalloc((void **)&dec->d_raw, dec->raw_bytes));
-	HIPCHK(hipMalloc((void **)&dec->d_quant, nframes * sizeof(JhQuant)));
-	HIPCHK(hipMalloc((void **)&dec->d_coefs, (size_t)nframes * G.nblk * 64 * sizeof(int16_t)));
-	HIPCHK(hipMemset(dec->d_raw, 0, dec->raw_bytes));
-	for (int f = 0; f < nframes; ++f) {
-		if (dec->parse_err[f] == 0) {
-			HIPCHK(hipMemcpy(dec->d_raw + file_off[f], jpg[f], jpg_len[f], hipMemcpyHostToDevice));
+	HIPCHK(dec->grow((void **)&dec->d_raw, dec->raw_bytes));
+	HIPCHK(dec->grow((void **)&dec->d_quant, nframes * sizeof(JhQuant)));
+	HIPCHK(dec->grow((void **)&dec->d_coefs, (size_t)nframes * G.nblk * 64 * sizeof(int16_t)));
+	// The codestreams go through ONE pinned staging buffer (kept between calls) and one DMA: the caller's
+	// memory is pageable as a rule, and a copy per frame from pageable memory runs at a third of the link's
+	// rate.  Frames are laid out as on the device, the gaps between them zero; a few threads fill it.
+	if (dec->stage_bytes < dec->raw_bytes) {
+		if (dec->h_stage) {
+			hipHostFree(dec->h_stage);
+			dec->h_stage = nullptr;
+			dec->stage_bytes = 0;
 		}
+		const size_t want = dec->raw_bytes + dec->raw_bytes / 4;
+		HIPCHK(hipHostMalloc((void **)&dec->h_stage, want, hipHostMallocDefault));
+		dec->stage_bytes = want;
+	}
+	{
+		uint8_t *stage = dec->h_stage;
+		const size_t total = dec->raw_bytes;
+		auto fill = [&](int f0, int f1) {
+			for (int f = f0; f < f1; ++f) {
+				const size_t begin = file_off[f];
+				const size_t end = f + 1 < nframes ? file_off[f + 1] : total;
+				size_t used = 0;
+				if (dec->parse_err[f] == 0) {
+					memcpy(stage + begin, jpg[f], jpg_len[f]);
+					used = jpg_len[f];
+				}
+				memset(stage + begin + used, 0, end - begin - used);
+			}
+		};
+		const int nthr = total > (8u << 20) && nframes >= 8 ? 4 : 1;
+		if (nthr == 1) {
+			fill(0, nframes);
+		} else {
+			std::vector<std::thread> pool;
+			for (int t = 0; t < nthr; ++t) {
+				pool.emplace_back(fill, (int)((long long)nframes * t / nthr), (int)((long long)nframes * (t + 1) / nthr));
+			}
+			for (std::thread &th : pool) {
+				th.join();
+			}
+		}
+		HIPCHK(hipMemcpy(dec->d_raw, stage, total, hipMemcpyHostToDevice));
 	}
 	HIPCHK(hipMemcpy(dec->d_quant, quant.data(), nframes * sizeof(JhQuant), hipMemcpyHostToDevice));
+	lap("upload");
 
 	for (DecPass &ps : dec->pass) {
 		JhDecodeWork &w = ps.work;

@@ -56,17 +56,44 @@ def combine_checksums(checksums):
 
 def decode_batches(frames, batch=256, device=0):
     """Decode `frames` (same geometry) in batches on `device`; yields (uint8 tensor [n, frame_bytes]
-    resident on the device, per-frame status list)."""
-    for i in range(0, len(frames), batch):
-        part = frames[i:i + batch]
-        d = binding.Decoder(device)
-        try:
-            d.prepare(part)
+    resident on the device, per-frame status list).  One decoder object serves every batch: its device
+    buffers only grow, so batches after the first allocate nothing."""
+    d = binding.Decoder(device)
+    try:
+        for i in range(0, len(frames), batch):
+            d.prepare(frames[i:i + batch])
             out = d.run()
             st = d.sync()
-        finally:
+            yield out, st
+    finally:
+        d.close()
+
+
+def decode_stream(frames, batch=256, device=0):
+    """The same, double-buffered: two decoder objects take turns, and while one
+    batch is decoded on a stream of its own, a helper thread parses the next batch's headers and uploads
+    its codestreams through the library's pinned staging buffer.  Yields (tensor, status) in order; the
+    tensor of a batch stays valid until the batch after the next one has been yielded."""
+    from concurrent.futures import ThreadPoolExecutor
+    torch = binding._torch()
+    decs = [binding.Decoder(device), binding.Decoder(device)]
+    stream = torch.cuda.Stream(device=device)
+    chunks = [frames[i:i + batch] for i in range(0, len(frames), batch)]
+    try:
+        with ThreadPoolExecutor(max_workers=1) as pool:
+            fut = pool.submit(decs[0].prepare, chunks[0]) if chunks else None
+            for i in range(len(chunks)):
+                fut.result()
+                d = decs[i & 1]
+                if i + 1 < len(chunks):
+                    fut = pool.submit(decs[(i + 1) & 1].prepare, chunks[i + 1])
+                with torch.cuda.stream(stream):
+                    out = d.run()
+                st = d.sync()
+                yield out, st
+    finally:
+        for d in decs:
             d.close()
-        yield out, st
 
 
 def gather_stats(local, dist=None):

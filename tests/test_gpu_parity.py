@@ -337,3 +337,30 @@ def test_restart_marker_encode_extension(hip, oracle, reference):
         assert rerr == 0 and np.array_equal(rpx, reference.decode(plain)[1])
         outs, st = hip.decode(jpgs)
         assert st == [0, 0] and np.array_equal(outs[0], rpx)
+
+
+def test_double_buffered_stream_equals_batches(hip, oracle):
+    """mjpeg.decode_stream (two decoders taking turns, uploads from a helper thread, decode on a stream of
+    its own) yields what decode_batches yields, batch after batch -- also when a decoder is prepared again
+    with a smaller and then a larger batch (its buffers only grow)."""
+    from jpeg_amd import mjpeg
+    frames = []
+    for i in range(11):
+        img = synth_image(160, 96, 3, 8, seed=300 + i, frame=i)
+        err, j, _ = oracle.encode(img, P=8, H=2, V=1, q=60 + 3 * i, optimize=i % 2)
+        assert err == 0
+        frames.append(j)
+    a = [(o.cpu().numpy().copy(), st) for o, st in mjpeg.decode_batches(frames, batch=4)]
+    b = [(o.cpu().numpy().copy(), st) for o, st in mjpeg.decode_stream(frames, batch=4)]
+    assert len(a) == len(b) == 3
+    for (oa, sa), (ob, sb) in zip(a, b):
+        assert sa == sb and all(s == 0 for s in sa)
+        assert np.array_equal(oa, ob)
+    d = hip.Decoder()
+    for part in (frames[:6], frames[6:8], frames):
+        d.prepare(part)
+        out = d.run()
+        assert d.sync() == [0] * len(part)
+        for k, px in enumerate(d.to_arrays(out)):
+            assert np.array_equal(px, oracle.decode(part[k])[1])
+    d.close()
