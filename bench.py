@@ -167,9 +167,15 @@ def main():
     out = dec.alloc_output()
     pix = cfg["X"] * cfg["Y"]
 
+    # the decode batch and the encode batch of a step are independent jobs: each runs on a stream of its
+    # own, so the short, narrow kernels of one pipeline (scans, walk rounds) overlap the wide ones of the other
+    s_dec, s_enc = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+
     def step():
-        dec.run(out)
-        enc.run(samples)
+        with torch.cuda.stream(s_dec):
+            dec.run(out)
+        with torch.cuda.stream(s_enc):
+            enc.run(samples)
 
     # correctness guard inside the bench: the decoded batch must be what the encoder was fed (lossy bound)
     dec.run(out)
