@@ -102,7 +102,10 @@ struct TileLayout {
 static void make_layout(const JhGeom &g, TileLayout *t)
 {
 	memset(t, 0, sizeof *t);
-	int G = 96 / g.B;
+#ifndef TILE_BLOCKS
+#define TILE_BLOCKS 96
+#endif
+	int G = TILE_BLOCKS / g.B;
 	G = G < 1 ? 1 : G;
 	G = G > g.m_x ? g.m_x : G;
 	t->G = G;
@@ -336,8 +339,11 @@ __global__ __launch_bounds__(256) void k_decode_pixels(const DecPixArgs a)
 			}
 #pragma unroll
 			for (int c = 0; c < oc; ++c) {
-				const int iv = (int)roundf(o[c]);               // frame.c:375-376
-				res[i * oc + c] = min(max(iv, 0), maxval);
+				// (int)roundf(x) clamped to [0, maxval] (frame.c:375-380): negative values end at 0 whatever
+				// their rounding; for x >= 0 half away from zero is floor(x) + (fract(x) >= 0.5)
+				const float y = fmaxf(o[c], 0.f);
+				const unsigned iv = (unsigned)y + (__builtin_amdgcn_fractf(y) >= 0.5f ? 1u : 0u);
+				res[i * oc + c] = (int)min(iv, (unsigned)maxval);
 			}
 		}
 		const int npx = min(4, X - gx0);
@@ -465,7 +471,7 @@ template <int NF, int SX, int SY>
 __global__ __launch_bounds__(256) void k_encode_pixels(const EncPixArgs a)
 {
 	extern __shared__ __align__(16) float tile[];
-	__shared__ float sqf[4][64];
+	__shared__ float2 sqf[4][64];     // x: divisor, y: its refined reciprocal (see quantise below)
 	__shared__ KTab kt;
 
 	const JhGeom &g = a.g;
@@ -481,7 +487,12 @@ __global__ __launch_bounds__(256) void k_encode_pixels(const EncPixArgs a)
 	const uint8_t *inf = a.in + (size_t)f * a.frame_stride;
 
 	for (int i = tid; i < 4 * 64; i += 256) {
-		sqf[i >> 6][i & 63] = (float)a.quant[f].q[i >> 6][i & 63];
+		// the first three steps of the correctly rounded fp32 division (the expansion hipcc emits for `/`):
+		// reciprocal estimate and one Newton step; they depend on the divisor only
+		const float d = (float)a.quant[f].q[i >> 6][i & 63];
+		const float r0 = __builtin_amdgcn_rcpf(d);
+		const float e0 = __builtin_fmaf(-d, r0, 1.0f);
+		sqf[i >> 6][i & 63] = make_float2(d, __builtin_fmaf(e0, r0, r0));
 	}
 	stage_ktab(kt, L, B, tid);
 
@@ -575,7 +586,7 @@ __global__ __launch_bounds__(256) void k_encode_pixels(const EncPixArgs a)
 		const BlockTask bt = block_task(kt, L, B, t >> 3);
 		const int x = t & 7;
 		float *p = tile + bt.addr + x;
-		const float *q = &sqf[bt.tq][x];
+		const float2 *q = &sqf[bt.tq][x];
 		float in[8], o[8];
 #pragma unroll
 		for (int y = 0; y < 8; ++y) {
@@ -584,8 +595,16 @@ __global__ __launch_bounds__(256) void k_encode_pixels(const EncPixArgs a)
 		dct1<false>(in, o);
 #pragma unroll
 		for (int u = 0; u < 8; ++u) {
-			// IEEE divide, round half away from zero
-			p[u * bt.pitch] = __int_as_float((int)roundf(o[u] / q[u * 8]));
+			// IEEE divide, round half away from zero.  o / d as the rest of the division's expansion: with
+			// operands in this range (|o| < 2^24, 1 <= d <= 65535) the scaling and fix-up steps of the
+			// general sequence are the identity unless the quotient is far below 0.5, where the rounding
+			// cannot see a difference; the arithmetic that decides every other case is the same, so the
+			// quotient is the correctly rounded one.
+			const float d = q[u * 8].x, r1 = q[u * 8].y, n = o[u];
+			const float q0 = n * r1;
+			const float q1 = __builtin_fmaf(__builtin_fmaf(-d, q0, n), r1, q0);
+			const float qq = __builtin_fmaf(__builtin_fmaf(-d, q1, n), r1, q1);
+			p[u * bt.pitch] = __int_as_float((int)roundf(qq));
 		}
 	}
 	__syncthreads();
