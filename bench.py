@@ -142,6 +142,9 @@ def main():
     ap.add_argument("--mjpeg-frames", type=int, default=256, help="1080p frames per GPU per step (extra line)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-mjpeg", action="store_true")
+    ap.add_argument("--one-stream", action="store_true",
+                    help="decode and encode on ONE stream (for rocprofv3 --stats: kernels of the two pipelines then "
+                         "do not overlap and their durations are the ones `kernel_ms` reports)")
     args = ap.parse_args()
 
     import torch
@@ -169,7 +172,8 @@ def main():
 
     # the decode batch and the encode batch of a step are independent jobs: each runs on a stream of its
     # own, so the short, narrow kernels of one pipeline (scans, walk rounds) overlap the wide ones of the other
-    s_dec, s_enc = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    s_dec = torch.cuda.Stream(dev)
+    s_enc = s_dec if args.one_stream else torch.cuda.Stream(dev)
 
     def step():
         with torch.cuda.stream(s_dec):
