@@ -115,6 +115,10 @@ int  jpeg_hip_decoder_get_timing(jpeg_hip_decoder *dec, const char **names, floa
  * (tests: all three paths must give identical results). */
 int  jpeg_hip_decoder_get_stats(const jpeg_hip_decoder *dec, int frame, uint32_t stats[4]);
 void jpeg_hip_decoder_set_debug(jpeg_hip_decoder *dec, int flags);
+/* parse_format() (decoder.c:472-659) ends in "unhandled marker" -> RET_FAILURE_FILE_UNSUPPORTED on APP9,
+ * APP10, APP15, DNL and JPGn segments (decoder.c:654-656); prepare() does the same by default.  on != 0
+ * (before prepare()): such segments are skipped by their length instead.  No counterpart in the reference. */
+void jpeg_hip_decoder_set_tolerant(jpeg_hip_decoder *dec, int on);
 /* compressed bytes actually consumed per frame (entropy-coded segment incl. RSTn), for roofline accounting */
 int  jpeg_hip_decoder_ecs_bytes(const jpeg_hip_decoder *dec, size_t *ecs_len);
 

@@ -30,7 +30,7 @@ EXPORTS = [
     "jpeg_hip_decoder_info", "jpeg_hip_decoder_frame_bytes", "jpeg_hip_decoder_run",
     "jpeg_hip_decoder_sync", "jpeg_hip_decoder_get_coefficients", "jpeg_hip_decoder_set_timing",
     "jpeg_hip_decoder_get_timing", "jpeg_hip_decoder_ecs_bytes", "jpeg_hip_decoder_get_stats",
-    "jpeg_hip_decoder_set_debug", "jpeg_hip_mjpeg_split",
+    "jpeg_hip_decoder_set_debug", "jpeg_hip_decoder_set_tolerant", "jpeg_hip_mjpeg_split",
     "jpeg_hip_encoder_create", "jpeg_hip_encoder_destroy", "jpeg_hip_encoder_configure",
     "jpeg_hip_encoder_info", "jpeg_hip_encoder_run", "jpeg_hip_encoder_sync",
     "jpeg_hip_encoder_get_jpeg", "jpeg_hip_encoder_device_jpeg", "jpeg_hip_encoder_get_coefficients",
@@ -99,6 +99,8 @@ def lib():
         L.jpeg_hip_decoder_get_stats.argtypes = [vp, C.c_int, C.POINTER(C.c_uint32)]
         L.jpeg_hip_decoder_set_debug.argtypes = [vp, C.c_int]
         L.jpeg_hip_decoder_set_debug.restype = None
+        L.jpeg_hip_decoder_set_tolerant.argtypes = [vp, C.c_int]
+        L.jpeg_hip_decoder_set_tolerant.restype = None
         L.jpeg_hip_mjpeg_split.argtypes = [C.c_char_p, sz, C.POINTER(sz), C.POINTER(sz), C.c_int]
         L.jpeg_hip_encoder_create.argtypes = [C.POINTER(vp), C.c_int]
         L.jpeg_hip_encoder_destroy.argtypes = [vp]
@@ -213,6 +215,10 @@ class Decoder:
 
     def set_debug(self, flags):
         self.L.jpeg_hip_decoder_set_debug(self.h, int(flags))
+
+    def set_tolerant(self, on=True):
+        """Skip APP9/APP10/APP15/DNL/JPGn segments instead of failing like the reference (call before prepare)."""
+        self.L.jpeg_hip_decoder_set_tolerant(self.h, int(on))
 
     def ecs_bytes(self):
         v = (C.c_size_t * self.n)()

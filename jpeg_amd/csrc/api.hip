@@ -205,6 +205,7 @@ struct jpeg_hip_decoder {
 	hipStream_t last_stream = nullptr;
 	bool ran = false;
 	int debug = 0;
+	bool tolerant = false;
 	StageTimer timer;
 
 	// Device buffers only grow: a decoder that is prepared again with a batch of similar size (Motion
@@ -292,10 +293,10 @@ struct ScanDesc {
 // SOI .. EOI of one frame: headers, and the list of scans.  Tables may be redefined between scans
 // (decoder.c:581-591 runs whenever a DHT comes); quantisation tables count as they stand at EOI,
 // where the reference dequantises (decoder.c:456-470).
-static int parse_frame(const uint8_t *p, size_t n, JhHeader *h, std::vector<ScanDesc> *scans)
+static int parse_frame(const uint8_t *p, size_t n, JhHeader *h, std::vector<ScanDesc> *scans, bool tolerant)
 {
 	scans->clear();
-	int err = jh_parse_headers(p, n, h);
+	int err = jh_parse_headers(p, n, h, tolerant);
 	if (err) {
 		return err;
 	}
@@ -384,7 +385,7 @@ extern "C" int jpeg_hip_decoder_prepare(jpeg_hip_decoder *dec, int nframes,
 
 	for (int f = 0; f < nframes; ++f) {
 		JhHeader &h = hdr[f];
-		int err = parse_frame(jpg[f], jpg_len[f], &h, &scans[f]);
+		int err = parse_frame(jpg[f], jpg_len[f], &h, &scans[f], dec->tolerant);
 		if (!err) {
 			err = jh_finish_geometry(&h.g);
 		}
@@ -828,6 +829,11 @@ extern "C" void jpeg_hip_decoder_set_debug(jpeg_hip_decoder *dec, int flags)
 	for (DecPass &ps : dec->pass) {
 		ps.work.debug = flags;
 	}
+}
+
+extern "C" void jpeg_hip_decoder_set_tolerant(jpeg_hip_decoder *dec, int on)
+{
+	dec->tolerant = on != 0;
 }
 
 extern "C" int jpeg_hip_decoder_ecs_bytes(const jpeg_hip_decoder *dec, size_t *ecs_len)

@@ -473,7 +473,12 @@ static int parse_segments(Reader &r, JhHeader *h, bool *eoi)
 		if (m == 0xffd8 || m == 0xff01) {                      // SOI, TEM
 			continue;
 		}
-		if ((m >= 0xffe0 && m <= 0xffe8) || (m >= 0xffeb && m <= 0xffee) || m == 0xffcc || m == 0xfffe) {
+		// The reference knows APP0-8 and APP11-14 only: APP9, APP10, APP15, DNL and the JPGn range end in
+		// "unhandled marker" (decoder.c:654-656).  That is kept, bug for bug, unless the caller asks for
+		// tolerance: then these segments are skipped by their length like the others.
+		const bool extra = h->tolerant && (m == 0xffe9 || m == 0xffea || m == 0xffef || m == 0xffdc ||
+		                                   (m >= 0xfff0 && m <= 0xfffd));
+		if ((m >= 0xffe0 && m <= 0xffe8) || (m >= 0xffeb && m <= 0xffee) || m == 0xffcc || m == 0xfffe || extra) {
 			// APPn except 9, 10, 15 (decoder.c:498-516), DAC (:647-653), COM (:635-641)
 			if (!r.ok(2)) {
 				return RET_FAILURE_FILE_IO;
@@ -645,10 +650,11 @@ static int parse_segments(Reader &r, JhHeader *h, bool *eoi)
 	}
 }
 
-int jh_parse_headers(const uint8_t *p, size_t n, JhHeader *h)
+int jh_parse_headers(const uint8_t *p, size_t n, JhHeader *h, bool tolerant)
 {
 	Reader r = {p, n, 0};
 	memset(h, 0, sizeof *h);
+	h->tolerant = tolerant;
 	for (int t = 0; t < 4; ++t) {
 		for (int i = 0; i < 64; ++i) {
 			h->Q[t][i] = 1;                                    // common.c:10-21

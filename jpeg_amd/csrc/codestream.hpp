@@ -21,10 +21,11 @@ struct JhHeader {
 	int scan_comp[JH_MAX_COMP];       // index into g.* of each scan component
 	size_t ecs_offset;                // first byte after the SOS header
 	bool have_sof;
+	bool tolerant;                    // set by the caller before parsing: skip APP9/APP10/APP15/DNL/JPGn instead of failing
 };
 
 // Parse SOI .. SOS of one codestream held in memory (decoder.c:472-659 restated).  Returns a RET_* code.
-int jh_parse_headers(const uint8_t *p, size_t n, JhHeader *h);
+int jh_parse_headers(const uint8_t *p, size_t n, JhHeader *h, bool tolerant = false);
 
 // Files with several scans (non-interleaved components, decoder.c:593-633): continue behind the entropy-coded
 // data of a scan.  Tables may be redefined on the way; *eoi = true when EOI came instead of another SOS.

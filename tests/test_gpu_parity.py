@@ -364,3 +364,26 @@ def test_double_buffered_stream_equals_batches(hip, oracle):
         for k, px in enumerate(d.to_arrays(out)):
             assert np.array_equal(px, oracle.decode(part[k])[1])
     d.close()
+
+
+def test_markers_the_reference_rejects(hip, oracle):
+    """APP9 / APP10 / APP15 / DNL end the reference's parse_format() with "unhandled marker"
+    (decoder.c:654-656): the default is the same status; set_tolerant() skips such segments."""
+    with open(golden_path("e_420_q75_o1.jpg"), "rb") as f:
+        jpg = f.read()
+    err, opx, _ = oracle.decode(jpg)
+    assert err == 0
+    for marker in (0xE9, 0xEA, 0xEF):
+        odd = jpg[:2] + bytes([0xFF, marker, 0x00, 0x06]) + b"abcd" + jpg[2:]
+        rerr = oracle.decode(odd)[0]
+        assert rerr == hip.RET_FAILURE_FILE_UNSUPPORTED
+        d = hip.Decoder()
+        with pytest.raises(hip.JpegError) as e:
+            d.prepare([odd])
+        assert e.value.code == rerr
+        d.set_tolerant(True)
+        d.prepare([odd])
+        out = d.run()
+        assert d.sync() == [0]
+        assert np.array_equal(d.to_arrays(out)[0], opx)
+        d.close()
