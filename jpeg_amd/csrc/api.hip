@@ -860,6 +860,8 @@ struct jpeg_hip_encoder {
 	JhQuant *d_quant = nullptr;
 	int16_t *d_coefs = nullptr;
 	JhHuffEnc *d_codes = nullptr;
+	JhDevSpec *d_specs = nullptr;
+	uint8_t *d_hdr_parts = nullptr;   // header bytes around the DHT segments (optimised mode builds headers on the device)
 	uint32_t *d_hist = nullptr, *d_wg_bits = nullptr, *d_us = nullptr, *d_chunk_ff = nullptr, *d_hdr_len = nullptr;
 	uint32_t *d_ivl_raw = nullptr, *d_ivl_padsum = nullptr, *d_ivl_eb = nullptr;
 	uint16_t *d_bitlen = nullptr;
@@ -874,7 +876,8 @@ struct jpeg_hip_encoder {
 	{
 		hipFree(d_quant); hipFree(d_coefs); hipFree(d_codes); hipFree(d_hist); hipFree(d_wg_bits);
 		hipFree(d_us); hipFree(d_chunk_ff); hipFree(d_hdr_len); hipFree(d_bitlen); hipFree(d_out); hipFree(d_state);
-		hipFree(d_ivl_raw); hipFree(d_ivl_padsum); hipFree(d_ivl_eb);
+		hipFree(d_ivl_raw); hipFree(d_ivl_padsum); hipFree(d_ivl_eb); hipFree(d_specs); hipFree(d_hdr_parts);
+		d_specs = nullptr; d_hdr_parts = nullptr;
 		d_ivl_raw = d_ivl_padsum = d_ivl_eb = nullptr;
 		d_quant = nullptr; d_coefs = nullptr; d_codes = nullptr; d_hist = d_wg_bits = d_us = d_chunk_ff = d_hdr_len = nullptr;
 		d_bitlen = nullptr; d_out = nullptr; d_state = nullptr;
@@ -904,16 +907,13 @@ extern "C" void jpeg_hip_encoder_destroy(jpeg_hip_encoder *enc)
 	}
 }
 
-struct TableSet {
-	JhHuffSpec t[2][4];
-};
-
-static int upload_codes_and_headers(jpeg_hip_encoder *e, int f0, int f1, const TableSet *specs, hipStream_t s)
+// default tables (e->ht) and the headers that carry them, for every frame; the optimised mode replaces both
+// on the device in every run (k_enc_adapt, k_enc_headers)
+static int upload_codes_and_headers(jpeg_hip_encoder *e, int f0, int f1, hipStream_t s)
 {
-	// specs == nullptr: every frame uses e->ht
 	std::vector<JhHuffEnc> codes((size_t)(f1 - f0) * 4);
 	for (int f = f0; f < f1; ++f) {
-		const JhHuffSpec(&ht)[2][4] = specs ? specs[f - f0].t : e->ht;
+		const JhHuffSpec(&ht)[2][4] = e->ht;
 		for (int tc = 0; tc < 2; ++tc) {
 			for (int th = 0; th < 2; ++th) {
 				int err = jh_build_enccodes(&ht[tc][th], &codes[(size_t)(f - f0) * 4 + tc * 2 + th]);
@@ -1012,6 +1012,37 @@ extern "C" int jpeg_hip_encoder_configure(jpeg_hip_encoder *enc, int nframes, in
 		HIPCHK(hipMalloc((void **)&enc->d_ivl_padsum, (size_t)nframes * (w.nivl + 1) * sizeof(uint32_t)));
 		HIPCHK(hipMalloc((void **)&enc->d_ivl_eb, (size_t)nframes * w.nivl * sizeof(uint32_t)));
 	}
+	{
+		// the header bytes in front of the DHT segments and behind them do not depend on the tables
+		std::vector<uint8_t> full;
+		jh_produce_headers(g, enc->Q, enc->ht, params->restart_interval, &full);
+		size_t pos = 2, pre = 0, suf = 0;
+		while (pos + 4 <= full.size()) {
+			const unsigned m = full[pos + 1];
+			if (m == 0xc4 && pre == 0) {
+				pre = pos;
+			}
+			if (pre != 0 && m != 0xc4) {
+				suf = pos;
+				break;
+			}
+			pos += 2 + (((size_t)full[pos + 2] << 8) | full[pos + 3]);
+		}
+		if (pre == 0 || suf == 0) {
+			return RET_FAILURE_LOGIC_ERROR;
+		}
+		HIPCHK(hipMalloc((void **)&enc->d_hdr_parts, full.size()));
+		HIPCHK(hipMemcpy(enc->d_hdr_parts, full.data(), pre, hipMemcpyHostToDevice));
+		HIPCHK(hipMemcpy(enc->d_hdr_parts + pre, full.data() + suf, full.size() - suf, hipMemcpyHostToDevice));
+		w.hdr_pre = enc->d_hdr_parts;
+		w.hdr_pre_len = (int)pre;
+		w.hdr_suf = enc->d_hdr_parts + pre;
+		w.hdr_suf_len = (int)(full.size() - suf);
+		w.ntab = g.Nf > 1 ? 2 : 1;
+		HIPCHK(hipMalloc((void **)&enc->d_specs, (size_t)nframes * 4 * sizeof(JhDevSpec)));
+		HIPCHK(hipMemset(enc->d_specs, 0, (size_t)nframes * 4 * sizeof(JhDevSpec)));
+		w.specs = enc->d_specs;
+	}
 	w.ivl_raw = enc->d_ivl_raw;
 	w.ivl_padsum = enc->d_ivl_padsum;
 	w.ivl_eb = enc->d_ivl_eb;
@@ -1035,7 +1066,7 @@ extern "C" int jpeg_hip_encoder_configure(jpeg_hip_encoder *enc, int nframes, in
 	enc->hdr_len.assign(nframes, 0);
 	enc->state.assign(nframes, JhEncState());
 	// default tables + headers for every frame (the optimised path overwrites them per run)
-	return upload_codes_and_headers(enc, 0, nframes, nullptr, nullptr);
+	return upload_codes_and_headers(enc, 0, nframes, nullptr);
 }
 
 extern "C" int jpeg_hip_encoder_info(const jpeg_hip_encoder *enc, jpeg_hip_frame_info *info)
@@ -1069,33 +1100,10 @@ extern "C" int jpeg_hip_encoder_run(jpeg_hip_encoder *enc, const void *d_samples
 	}
 	enc->timer.end(s);
 	if (enc->prm.optimize) {
-		// write_ecs_dry() (encoder.c:525-558): histograms on the device, Annex K.2 on the host
-		// (<= 257 symbols per table, serial: SURVEY.md 8a-a18), tables back to the device.
-		if (jh_launch_enc_histogram(w, g, s, &th)) {
+		// write_ecs_dry() (encoder.c:525-558): symbol statistics, then adapt_huffman_table (huffman.c:508-537)
+		// and the headers that carry the new tables -- all on the device, nothing waits for the host
+		if (jh_launch_enc_histogram(w, g, s, &th) || jh_launch_enc_adapt(w, g, s, &th)) {
 			return RET_FAILURE_LOGIC_ERROR;
-		}
-		std::vector<uint32_t> hist((size_t)enc->nframes * 4 * 257);
-		HIPCHK(hipMemcpyAsync(hist.data(), enc->d_hist, hist.size() * 4, hipMemcpyDeviceToHost, s));
-		HIPCHK(hipStreamSynchronize(s));
-		std::vector<TableSet> specs(enc->nframes);
-		const int ntab = g.Nf > 1 ? 2 : 1;
-		for (int f = 0; f < enc->nframes; ++f) {
-			memcpy(specs[f].t, enc->ht, sizeof enc->ht);
-			for (int tc = 0; tc < 2; ++tc) {
-				for (int th = 0; th < ntab; ++th) {
-					uint64_t freq[257];
-					const uint32_t *h = &hist[((size_t)f * 4 + tc * 2 + th) * 257];
-					for (int i = 0; i < 256; ++i) {
-						freq[i] = h[i];
-					}
-					freq[256] = 1;                         // reserved code point (common.c:219)
-					jh_adapt_table(freq, &specs[f].t[tc][th]);
-				}
-			}
-		}
-		int err = upload_codes_and_headers(enc, 0, enc->nframes, specs.data(), s);
-		if (err) {
-			return err;
 		}
 	}
 	if (jh_launch_enc_entropy(w, g, s, &th)) {
@@ -1113,6 +1121,9 @@ extern "C" int jpeg_hip_encoder_sync(jpeg_hip_encoder *enc, int *frame_status, s
 	HIPCHK(hipSetDevice(enc->device));
 	HIPCHK(hipStreamSynchronize(enc->last_stream));
 	HIPCHK(hipMemcpy(enc->state.data(), enc->d_state, enc->nframes * sizeof(JhEncState), hipMemcpyDeviceToHost));
+	if (enc->prm.optimize) {
+		HIPCHK(hipMemcpy(enc->hdr_len.data(), enc->d_hdr_len, enc->nframes * sizeof(uint32_t), hipMemcpyDeviceToHost));
+	}
 	int worst = RET_SUCCESS;
 	for (int f = 0; f < enc->nframes; ++f) {
 		const JhEncState &st = enc->state[f];

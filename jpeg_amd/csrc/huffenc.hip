@@ -164,6 +164,236 @@ int jh_launch_enc_histogram(const JhEncodeWork &w, const JhGeom &g, hipStream_t 
 	return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
+// ---------------------------------------------------------------------------------------- table adaptation
+
+// adapt_huffman_table (huffman.c:508-537) on the device, one wave per (frame, table): no trip to the host
+// between the statistics and the bit packing.
+//   Figure K.1 (huffman.c:366-411): the two least frequent entries are merged until one is left; among
+//     equals the LARGEST index is taken (huffman.c:338).  The reference walks two linked lists to add one
+//     to the code size of every member of both trees; here every symbol carries the index of its tree's
+//     head, and the lanes update the members of both trees side by side.
+//   Figures K.2-K.4 (huffman.c:413-506): sizes counted, limited to 16 bits, the reserved all-ones code
+//     point removed, symbols listed by (size, value).
+//   Then Annex C codes in the first-match sense of value_to_vlc (huffman.c:228-253).
+__global__ __launch_bounds__(64) void k_enc_adapt(const EncArgs a)
+{
+	__shared__ uint32_t freq[320];
+	__shared__ uint16_t head[320];
+	__shared__ uint8_t csize[320];
+	__shared__ int bits[34];
+	__shared__ uint8_t outv[256];
+	__shared__ int first_idx[18];
+	__shared__ uint32_t first_code[18];
+	const JhEncodeWork &w = a.w;
+	const int t = blockIdx.x, f = blockIdx.y, lane = threadIdx.x;
+	if ((t & 1) >= w.ntab) {
+		return;                                            // table id not in use: the default codes stay
+	}
+	const uint32_t *h = w.hist + ((size_t)f * 4 + t) * 257;
+	for (int i = lane; i < 320; i += 64) {
+		freq[i] = i < 256 ? h[i] : (i == 256 ? 1u : 0u);   // [256]: the reserved code point (common.c:219)
+		head[i] = (uint16_t)i;
+		csize[i] = 0;
+	}
+	if (lane < 34) {
+		bits[lane] = 0;
+	}
+	__syncthreads();
+	// ---- Figure K.1
+	for (;;) {
+		int v[2];
+#pragma unroll
+		for (int pick = 0; pick < 2; ++pick) {
+			unsigned long long best = ~0ull;               // (frequency << 16) | (0xffff - index): least frequent, then largest index
+#pragma unroll
+			for (int j = 0; j < 5; ++j) {
+				const int i = lane + 64 * j;
+				const uint32_t fr = freq[i];
+				if (fr != 0 && !(pick == 1 && i == v[0])) {
+					const unsigned long long key = ((unsigned long long)fr << 16) | (unsigned)(0xffff - i);
+					best = key < best ? key : best;
+				}
+			}
+#pragma unroll
+			for (int o = 32; o > 0; o >>= 1) {
+				const unsigned long long other = __shfl_xor(best, o, 64);
+				best = other < best ? other : best;
+			}
+			v[pick] = best == ~0ull ? -1 : 0xffff - (int)(best & 0xffffu);
+		}
+		if (v[1] < 0) {
+			break;
+		}
+		const int v1 = v[0], v2 = v[1];
+#pragma unroll
+		for (int j = 0; j < 5; ++j) {
+			const int i = lane + 64 * j;
+			const int hd = head[i];
+			if (i <= 256 && (hd == v1 || hd == v2)) {
+				csize[i] = (uint8_t)min((int)csize[i] + 1, 255);
+				head[i] = (uint16_t)v1;
+			}
+		}
+		if (lane == 0) {
+			freq[v1] += freq[v2];
+			freq[v2] = 0;
+		}
+		__syncthreads();
+	}
+	// ---- Figure K.2: how many codes of every size
+	for (int i = lane; i <= 256; i += 64) {
+		const int cs = csize[i];
+		if (cs > 0 && cs <= 32) {
+			atomicAdd(&bits[cs], 1);
+		}
+	}
+	__syncthreads();
+	// ---- Figure K.3: no code longer than 16 bits; then the reserved code point goes
+	if (lane == 0) {
+		for (int i = 32; i > 16;) {
+			if (bits[i] > 0) {
+				int j = i - 1;
+				do {
+					j--;
+				} while (j > 0 && bits[j] <= 0);
+				bits[i] -= 2;
+				bits[i - 1] += 1;
+				bits[j + 1] += 2;
+				bits[j] -= 1;
+			} else {
+				i--;
+			}
+		}
+		int top = 16;
+		while (top > 0 && bits[top] == 0) {
+			top--;
+		}
+		if (top > 0) {
+			bits[top]--;
+		}
+		// Annex C: first index and first code of every length (Figures C.1, C.2)
+		int k = 0;
+		uint32_t code = 0;
+		for (int len = 1; len <= 16; ++len) {
+			first_idx[len] = k;
+			first_code[len] = code;
+			k += bits[len];
+			code = (code + (uint32_t)bits[len]) << 1;
+		}
+		first_idx[17] = k;
+	}
+	// ---- Figure K.4: symbols by (size, value); sizes before the limiting count, as in the reference
+	int k = 0;
+	for (int sz = 1; sz <= 32; ++sz) {
+#pragma unroll
+		for (int j = 0; j < 4; ++j) {
+			const int sym = lane + 64 * j;
+			const bool hit = csize[sym] == sz;
+			const unsigned long long m = __ballot(hit);
+			if (hit) {
+				const int pos = k + __popcll(m & ((1ull << lane) - 1ull));
+				if (pos < 256) {
+					outv[pos] = (uint8_t)sym;
+				}
+			}
+			k += __popcll(m);
+		}
+	}
+	__syncthreads();
+	const int mt = min(first_idx[17], 256);
+	JhDevSpec *spec = w.specs + (size_t)f * 4 + t;
+	if (lane < 16) {
+		spec->L[lane] = (uint8_t)bits[lane + 1];
+	}
+	for (int i = lane; i < 256; i += 64) {
+		spec->V[i] = i < mt ? outv[i] : 0;
+	}
+	if (lane == 0) {
+		spec->mt = (uint32_t)mt;
+	}
+	// ---- codes for the packer: (code << 8) | size, 0 = symbol absent
+	JhHuffEnc *enc = w.codes + (size_t)f * 4 + t;
+	for (int i = lane; i < 256; i += 64) {
+		enc->code[i] = 0;
+	}
+	__syncthreads();
+	for (int p = lane; p < mt; p += 64) {
+		int len = 1;
+		while (len < 16 && p >= first_idx[len + 1]) {
+			len++;
+		}
+		enc->code[outv[p]] = ((first_code[len] + (uint32_t)(p - first_idx[len])) << 8) | (uint32_t)len;
+	}
+}
+
+// produce_codestream's header part (encoder.c:589-645) for the adapted tables: the bytes in front of the
+// DHT segments and behind them are the same for every frame of the batch.
+__global__ __launch_bounds__(256) void k_enc_headers(const EncArgs a)
+{
+	__shared__ uint32_t seg_off[5];
+	const JhEncodeWork &w = a.w;
+	const int f = blockIdx.x, tid = threadIdx.x;
+	const JhDevSpec *specs = w.specs + (size_t)f * 4;
+	uint8_t *out = w.out + (size_t)f * w.out_stride;
+	// DHT order: DC then AC for table id 0, then for id 1 (encoder.c:620-630); tables are stored [Tc*2+Th]
+	const int order[4] = {0, 2, 1, 3};
+	const int nseg = 2 * w.ntab;
+	if (tid == 0) {
+		uint32_t o = (uint32_t)w.hdr_pre_len;
+		for (int i = 0; i < nseg; ++i) {
+			seg_off[i] = o;
+			o += 2u + 2u + 17u + specs[order[i]].mt;
+		}
+		seg_off[4] = o;
+		w.hdr_len[f] = o + (uint32_t)w.hdr_suf_len;
+	}
+	__syncthreads();
+	const uint32_t dht_end = seg_off[4];
+	for (int i = tid; i < w.hdr_pre_len; i += 256) {
+		out[i] = w.hdr_pre[i];
+	}
+	for (int i = tid; i < w.hdr_suf_len; i += 256) {
+		out[dht_end + i] = w.hdr_suf[i];
+	}
+	for (int sg = 0; sg < nseg; ++sg) {
+		const int t = order[sg];
+		const JhDevSpec &sp = specs[t];
+		uint8_t *o = out + seg_off[sg];
+		const uint32_t len = 2u + 17u + sp.mt;
+		for (uint32_t i = tid; i < 4u + 17u + sp.mt; i += 256) {
+			uint8_t b;
+			if (i == 0) {
+				b = 0xff;
+			} else if (i == 1) {
+				b = 0xc4;
+			} else if (i == 2) {
+				b = (uint8_t)(len >> 8);
+			} else if (i == 3) {
+				b = (uint8_t)len;
+			} else if (i == 4) {
+				b = (uint8_t)(((t >> 1) << 4) | (t & 1));      // Tc << 4 | Th
+			} else if (i < 21) {
+				b = sp.L[i - 5];
+			} else {
+				b = sp.V[i - 21];
+			}
+			o[i] = b;
+		}
+	}
+}
+
+int jh_launch_enc_adapt(const JhEncodeWork &w, const JhGeom &g, hipStream_t s, const JhTimerHook *th)
+{
+	EncArgs a;
+	a.w = w;
+	a.g = g;
+	JH_T_BEGIN(th, "k_enc_adapt", s);
+	hipLaunchKernelGGL(k_enc_adapt, dim3(4, w.nframes), dim3(64), 0, s, a);
+	hipLaunchKernelGGL(k_enc_headers, dim3(w.nframes), dim3(256), 0, s, a);
+	JH_T_END(th, s);
+	return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 // ---------------------------------------------------------------------------------------- bit lengths
 
 __device__ __forceinline__ unsigned block_sum(unsigned v, unsigned *scratch)

@@ -112,9 +112,15 @@ struct JhEncState {               // per frame, written by the device
 	uint32_t ecs_bytes;           // bytes after 0xFF stuffing (+ RSTn markers)
 };
 
+struct JhDevSpec {                // a Huffman table specification as a DHT segment carries it (common.h:85-91)
+	uint8_t L[16];
+	uint8_t V[256];
+	uint32_t mt;                  // number of symbols
+};
+
 struct JhEncodeWork {
 	const int16_t *coefs;         // [frame][nblk][64] zig-zag
-	const JhHuffEnc *codes;       // [frame][Tc*2+Th]: DC0, DC1, AC0, AC1 (table ids 0/1 only, as the encoder uses)
+	JhHuffEnc *codes;             // [frame][Tc*2+Th]: DC0, DC1, AC0, AC1 (table ids 0/1 only, as the encoder uses)
 	uint32_t *hist;               // [frame][4][257] symbol counts (optimised tables)
 	uint16_t *bitlen;             // [frame][nblk]
 	uint32_t *wg_bits;            // [frame][nwg] per-workgroup sums, then exclusive bases
@@ -123,7 +129,12 @@ struct JhEncodeWork {
 	uint32_t *chunk_ff;           // [frame][nchunk] 0xFF counts per chunk, then exclusive bases
 	uint8_t *out;                 // final codestreams: frame stride out_stride, ECS starts at hdr_len[frame]
 	size_t out_stride;
-	const uint32_t *hdr_len;      // [frame]
+	uint32_t *hdr_len;            // [frame]
+	JhDevSpec *specs;             // [frame][Tc*2+Th] tables adapted on the device (optimised mode)
+	const uint8_t *hdr_pre;       // header bytes in front of the DHT segments (SOI, DQT, SOF0), same for every frame
+	const uint8_t *hdr_suf;       // header bytes behind them ([DRI], SOS)
+	int hdr_pre_len, hdr_suf_len;
+	int ntab;                     // table ids in use: 1 (one component) or 2
 	JhEncState *state;
 	int nframes;
 	int nwg;                      // workgroups (256 blocks each) per frame
@@ -136,4 +147,5 @@ struct JhEncodeWork {
 };
 
 int jh_launch_enc_histogram(const JhEncodeWork &w, const JhGeom &g, hipStream_t s, const JhTimerHook *th);
+int jh_launch_enc_adapt(const JhEncodeWork &w, const JhGeom &g, hipStream_t s, const JhTimerHook *th);
 int jh_launch_enc_entropy(const JhEncodeWork &w, const JhGeom &g, hipStream_t s, const JhTimerHook *th);
