@@ -507,7 +507,8 @@ extern "C" int jpeg_hip_decoder_prepare(jpeg_hip_decoder *dec, int nframes,
 			fr.sub_off = (uint32_t)ps.sub_off;
 			fr.sub_cap = (uint32_t)(cs_cap / JH_SUBSEQ_BYTES + 2);
 			fr.seg_off = (uint32_t)ps.seg_off;
-			fr.seg_cap = (uint32_t)((sd.Ri > 0 ? (ps.g.nmcu + sd.Ri - 1) / sd.Ri : 1) + 64);
+			// a single-component scan's interval counts blocks by the standard (the reference ignores Ri)
+			fr.seg_cap = (uint32_t)((sd.Ri > 0 ? ((ps.comp >= 0 ? ps.g.nblk : ps.g.nmcu) + sd.Ri - 1) / sd.Ri : 1) + 64);
 			fr.chunk_off = (uint32_t)ps.chunk_off;
 			fr.wg_off = (uint32_t)ps.wg_off;
 			ps.wg_off += fr.sub_cap / JH_SEQ_OWN + 2;
@@ -1128,7 +1129,10 @@ extern "C" int jpeg_hip_encoder_sync(jpeg_hip_encoder *enc, int *frame_status, s
 	for (int f = 0; f < enc->nframes; ++f) {
 		const JhEncState &st = enc->state[f];
 		int r = RET_SUCCESS;
-		if (st.status & JH_EST_DC_RANGE) {
+		if (st.first_err != 0) {
+			// the error of the first failing block in scan order, as the serial encoder meets it
+			r = ((~st.first_err) & 1u) ? JPEG_HIP_ERR_NO_CODE : JPEG_HIP_ERR_DC_RANGE;
+		} else if (st.status & JH_EST_DC_RANGE) {
 			r = JPEG_HIP_ERR_DC_RANGE;
 		} else if (st.status & JH_EST_NO_CODE) {
 			r = JPEG_HIP_ERR_NO_CODE;

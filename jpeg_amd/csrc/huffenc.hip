@@ -476,6 +476,8 @@ __global__ __launch_bounds__(256) void k_enc_bitlen(const EncArgs a)
 	}
 	if (err) {
 		atomicOr(&w.state[f].status, err);
+		// inside a block the range test comes first (encoder.c:447 before write_block)
+		atomicMax(&w.state[f].first_err, ~((uint32_t)blk * 2u + ((err & JH_EST_DC_RANGE) ? 0u : 1u)));
 	}
 	const unsigned total = block_sum(bits, scratch);
 	if (threadIdx.x == 0) {

@@ -110,6 +110,8 @@ struct JhEncState {               // per frame, written by the device
 	uint32_t total_bits;          // entropy-coded bits before padding
 	uint32_t us_bytes;            // bytes of the unstuffed stream (after padding with 1s)
 	uint32_t ecs_bytes;           // bytes after 0xFF stuffing (+ RSTn markers)
+	uint32_t first_err;           // ~(block * 2 + kind) of the FIRST failing block in scan order (kind 0: DC range,
+	                              // 1: missing code), 0 = none: the serial encoder stops at that block with that error
 };
 
 struct JhDevSpec {                // a Huffman table specification as a DHT segment carries it (common.h:85-91)

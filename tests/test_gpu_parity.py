@@ -387,3 +387,14 @@ def test_markers_the_reference_rejects(hip, oracle):
         assert d.sync() == [0]
         assert np.array_equal(d.to_arrays(out)[0], opx)
         d.close()
+
+
+def test_randomised_cases(hip, oracle):
+    """A bounded run of tools/fuzz.py: random geometry, sampling, precision, quality, table mode, restart
+    interval and batch size; codestream bytes, coefficients and samples identical to the oracle's."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz.py"), "60", "7"], cwd=root,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
