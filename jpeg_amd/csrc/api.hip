@@ -771,8 +771,8 @@ extern "C" int jpeg_hip_decoder_sync(jpeg_hip_decoder *dec, int *frame_status)
 			dec->ecs_len[f] += ds.term_pos - fr.raw_begin;
 			if (ds.status & JH_ST_SEG_OVERFLOW) {
 				st = RET_FAILURE_FILE_UNSUPPORTED;
-			} else if (ds.term_pos >= fr.raw_end) {
-				st = RET_FAILURE_FILE_IO;            // no EOI: read_marker() hits end of file (io.c:197)
+			} else if (ds.term_pos + 1 >= fr.raw_end) {
+				st = RET_FAILURE_FILE_IO;            // no EOI (or a lone FF as the last byte): read_marker() hits end of file (io.c:197)
 			} else if (pi + 1 == dec->pass.size() && dec->pass[pi].comp < 0 && ds.term_marker != 0xd9) {
 				st = RET_FAILURE_FILE_UNSUPPORTED;   // a scan of all components followed by more than EOI: not on the GPU path
 			}
