@@ -17,7 +17,7 @@
 
 // ---- Huffman decode look-up ---------------------------------------------------------------
 #define JH_LUT_BITS 10                // fast table index width
-#define JH_SUBSEQ_BITS 1024           // bits per speculative sub-sequence (one thread each)
+#define JH_SUBSEQ_BITS 2048           // bits per speculative sub-sequence (one thread each)
 #define JH_SUBSEQ_BYTES (JH_SUBSEQ_BITS / 8)
 #define JH_CHAIN_MAX 16               // steps a speculative chain may walk before it is cut
 #define JH_SEQ_OWN (256 - JH_CHAIN_MAX)   // sub-sequences owned by one workgroup (the rest are ghosts)
