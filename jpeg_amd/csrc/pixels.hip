@@ -187,36 +187,35 @@ struct DecPixArgs {
 
 // 4 horizontally adjacent frame pixels of component c: transform_components_to_frame (frame.c:63-76)
 // read backwards, frame(x, y) <- component(x / step_x, y / step_y)
+// SX: the component's horizontal step when the launcher knows it (1, 2), 0 = look it up.  A known step
+// lets the compiler see which of the four pixels share a chroma sample, and with it their colour products.
+template <int SX>
 __device__ __forceinline__ void fetch4(const float *tile, const TileLayout &L, const JhGeom &g, int c,
                                        int row, int px0, float (&s)[4])
 {
 	const int cy = (row * L.sy_magic[c]) >> 16;
 	const float *p = tile + L.base[c] + cy * L.pitch[c];
-	switch (g.step_x[c]) {
-	case 1: {
+	const int step = SX ? SX : g.step_x[c];
+	if (step == 1) {
 		const float4 v = *reinterpret_cast<const float4 *>(p + px0);
 		s[0] = v.x; s[1] = v.y; s[2] = v.z; s[3] = v.w;
-		break;
-	}
-	case 2: {
+	} else if (step == 2) {
 		const float2 v = *reinterpret_cast<const float2 *>(p + (px0 >> 1));
 		s[0] = s[1] = v.x;
 		s[2] = s[3] = v.y;
-		break;
-	}
-	case 4:
+	} else if (step == 4) {
 		s[0] = s[1] = s[2] = s[3] = p[px0 >> 2];
-		break;
-	default:
+	} else {
 #pragma unroll
 		for (int i = 0; i < 4; ++i) {
 			s[i] = p[((px0 + i) * L.sx_magic[c]) >> 16];
 		}
-		break;
 	}
 }
 
-template <int NF>
+// CSX: horizontal step of the components behind the first one when they all share it and the first has
+// step 1 (what every subsampled YCbCr frame looks like), else 0
+template <int NF, int CSX>
 __global__ __launch_bounds__(256) void k_decode_pixels(const DecPixArgs a)
 {
 	extern __shared__ __align__(16) float tile[];
@@ -312,7 +311,13 @@ __global__ __launch_bounds__(256) void k_decode_pixels(const DecPixArgs a)
 		float s[NF][4];
 #pragma unroll
 		for (int c = 0; c < NF; ++c) {
-			fetch4(tile, L, g, c, row, px0, s[c]);
+			if (CSX != 0 && c == 0) {
+				fetch4<1>(tile, L, g, c, row, px0, s[c]);
+			} else if (CSX != 0 && (NF != 4 || c != NF - 1)) {
+				fetch4<CSX>(tile, L, g, c, row, px0, s[c]);
+			} else {
+				fetch4<0>(tile, L, g, c, row, px0, s[c]);
+			}
 		}
 		int res[4 * oc];
 #pragma unroll
@@ -392,15 +397,26 @@ int jh_launch_decode_pixels(const JhGeom &g, int nframes, const int16_t *coefs, 
 	a.g = g;
 	dim3 grid((g.m_x + a.L.G - 1) / a.L.G, g.m_y, nframes);
 	const size_t lds = (size_t)a.L.lds_floats * sizeof(float);
+	// chroma step known at compile time for the common layouts
+	int csx = 0;
+	if (g.Nf == 3 && g.step_x[0] == 1 && g.step_x[1] == g.step_x[2] && (g.step_x[1] == 1 || g.step_x[1] == 2)) {
+		csx = g.step_x[1];
+	}
 	switch (g.Nf) {
 	case 1:
-		hipLaunchKernelGGL(k_decode_pixels<1>, grid, dim3(256), lds, stream, a);
+		hipLaunchKernelGGL((k_decode_pixels<1, 0>), grid, dim3(256), lds, stream, a);
 		break;
 	case 3:
-		hipLaunchKernelGGL(k_decode_pixels<3>, grid, dim3(256), lds, stream, a);
+		if (csx == 1) {
+			hipLaunchKernelGGL((k_decode_pixels<3, 1>), grid, dim3(256), lds, stream, a);
+		} else if (csx == 2) {
+			hipLaunchKernelGGL((k_decode_pixels<3, 2>), grid, dim3(256), lds, stream, a);
+		} else {
+			hipLaunchKernelGGL((k_decode_pixels<3, 0>), grid, dim3(256), lds, stream, a);
+		}
 		break;
 	case 4:
-		hipLaunchKernelGGL(k_decode_pixels<4>, grid, dim3(256), lds, stream, a);
+		hipLaunchKernelGGL((k_decode_pixels<4, 0>), grid, dim3(256), lds, stream, a);
 		break;
 	default:
 		return -1;
