@@ -362,6 +362,9 @@ __device__ __forceinline__ void flush_blocks(bool fin, int fblk, int4 *bufs, int
 	}
 }
 
+// REMAP: the scan codes one component of several (JhRemap.mode 1); a kernel of its own, so that the usual
+// case carries neither the test nor the registers
+template <bool REMAP>
 __global__ __launch_bounds__(WR_THREADS) void k_huff_write(const HuffArgs a)
 {
 	extern __shared__ __align__(16) unsigned char smem[];
@@ -395,7 +398,7 @@ __global__ __launch_bounds__(WR_THREADS) void k_huff_write(const HuffArgs a)
 	const uint32_t nseg = min(fs.nseg, fr.seg_cap - 1);
 	const int B = a.g.B, nblk = a.g.nblk;
 	const JhRemap rm = w.rm;
-	int4 *frame_coefs = reinterpret_cast<int4 *>(w.coefs + (size_t)f * (rm.mode ? rm.nblk_full : nblk) * 64);
+	int4 *frame_coefs = reinterpret_cast<int4 *>(w.coefs + (size_t)f * (REMAP ? rm.nblk_full : nblk) * 64);
 	int16_t *mybuf = reinterpret_cast<int16_t *>(bufs + tid * 8);
 	int *dcs = &dcs_all[0][tid];
 
@@ -566,7 +569,7 @@ __global__ __launch_bounds__(WR_THREADS) void k_huff_write(const HuffArgs a)
 				if (done) {
 					fin = true;
 					fblk = (own && blk >= 0 && blk < nblk && blk < limit_blk) ? blk : -1;
-					if (rm.mode && fblk >= 0) {
+					if (REMAP && fblk >= 0) {
 						fblk = remap_block(rm, fblk);
 					}
 					own = true;
@@ -711,13 +714,17 @@ int jh_launch_huff_decode(const JhDecodeWork &w, const JhGeom &g, hipStream_t s,
 	}
 	// one launch configuration for the batch: LDS for the largest table set of any frame
 	const size_t lds = sizeof(JhHuffLut) * (size_t)w.max_luts + (size_t)WR_THREADS * 128;
-	if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_huff_write), hipFuncAttributeMaxDynamicSharedMemorySize,
-	                        (int)lds) != hipSuccess) {
+	const void *wr = w.rm.mode ? reinterpret_cast<const void *>(k_huff_write<true>) : reinterpret_cast<const void *>(k_huff_write<false>);
+	if (hipFuncSetAttribute(wr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
 		return -1;
 	}
 	dim3 gsub((w.max_subs + WR_THREADS - 1) / WR_THREADS, w.nframes);
 	JH_T_BEGIN(th, "k_huff_write", s);
-	hipLaunchKernelGGL(k_huff_write, gsub, dim3(WR_THREADS), lds, s, a);
+	if (w.rm.mode) {
+		hipLaunchKernelGGL(k_huff_write<true>, gsub, dim3(WR_THREADS), lds, s, a);
+	} else {
+		hipLaunchKernelGGL(k_huff_write<false>, gsub, dim3(WR_THREADS), lds, s, a);
+	}
 	JH_T_END(th, s);
 	JH_T_BEGIN(th, "k_huff_fixup", s);
 	hipLaunchKernelGGL(k_huff_fixup, dim3(w.nframes), dim3(64), 0, s, a);
