@@ -138,7 +138,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames", type=int, default=64, help="4K frames per GPU per step")
+    ap.add_argument("--frames", type=int, default=128, help="4K frames per GPU per step")
     ap.add_argument("--mjpeg-frames", type=int, default=256, help="1080p frames per GPU per step (extra line)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-mjpeg", action="store_true")
