@@ -62,7 +62,7 @@ def timed(torch, fn, steps, warmup, dist):
         dist.barrier()
     t = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([t], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([t], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         t = float(tt.item())
     return t
@@ -142,6 +142,8 @@ def main():
     ap.add_argument("--mjpeg-frames", type=int, default=256, help="1080p frames per GPU per step (extra line)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-mjpeg", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend; gloo rehearses the multi-rank path "
+                                                      "with several ranks on ONE GPU (RCCL refuses that)")
     ap.add_argument("--one-stream", action="store_true",
                     help="decode and encode on ONE stream (for rocprofv3 --stats: kernels of the two pipelines then "
                          "do not overlap and their durations are the ones `kernel_ms` reports)")
@@ -152,11 +154,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    if args.backend != "nccl":
+        local = local % torch.cuda.device_count()          # rehearsal: ranks share the GPUs there are
     if world > 1:
         import torch.distributed as dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
-        dist_mod.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            dist_mod.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist_mod.init_process_group(args.backend, rank=rank, world_size=world)
         dist = dist_mod
     else:
         torch.cuda.set_device(local)
