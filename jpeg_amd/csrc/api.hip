@@ -155,7 +155,7 @@ struct StageTimer {
 // quantisation tables and the coefficient buffer are shared.
 struct DecPass {
 	JhGeom g;                         // what the Huffman kernels see (B = 1 for a single-component scan)
-	int comp = -1;                    // component of a single-component scan, -1 = all (interleaved)
+	int comp = -1;                    // component of a single-component scan, -1 = all (interleaved), -2 = some
 	std::vector<JhDecFrame> frames;
 	std::vector<JhDecState> state;
 	uint8_t *d_cs = nullptr;
@@ -283,7 +283,8 @@ static bool same_geometry(const JhGeom &a, const JhGeom &b)
 
 // one scan of one frame as the host found it
 struct ScanDesc {
-	int comp;                         // -1: all components interleaved
+	int comp;                         // -1: all components interleaved, -2: some of them (cs[0 .. ncs)), else the one
+	int ncs, cs[JH_MAX_COMP];         // the scan's components in the order of its header
 	size_t ecs_begin, ecs_end;        // ecs_end: end of the bytes the device may look at
 	int Td[JH_MAX_COMP], Ta[JH_MAX_COMP];
 	JhHuffSpec ht[2][4];              // the tables in force when the scan started
@@ -303,6 +304,10 @@ static int parse_frame(const uint8_t *p, size_t n, JhHeader *h, std::vector<Scan
 	auto describe = [&](int comp, size_t end) {
 		ScanDesc sd;
 		sd.comp = comp;
+		sd.ncs = h->Ns;
+		for (int j = 0; j < JH_MAX_COMP; ++j) {
+			sd.cs[j] = j < h->Ns ? h->scan_comp[j] : -1;
+		}
 		sd.ecs_begin = h->ecs_offset;
 		sd.ecs_end = end;
 		for (int k = 0; k < JH_MAX_COMP; ++k) {
@@ -321,17 +326,20 @@ static int parse_frame(const uint8_t *p, size_t n, JhHeader *h, std::vector<Scan
 		describe(-1, n);
 		return RET_SUCCESS;
 	}
-	// one component per scan; scans of 2 .. Nf-1 components are not on the GPU path
+	// several scans, each with one component or some of them
 	unsigned seen = 0;
 	for (;;) {
-		if (h->Ns != 1) {
+		if (h->Ns >= h->g.ncomp) {
 			return RET_FAILURE_FILE_UNSUPPORTED;
 		}
-		const int k = h->scan_comp[0];
-		if (seen & (1u << k)) {
-			return RET_FAILURE_FILE_UNSUPPORTED;           // a component coded twice
+		for (int j = 0; j < h->Ns; ++j) {
+			const int k = h->scan_comp[j];
+			if (seen & (1u << k)) {
+				return RET_FAILURE_FILE_UNSUPPORTED;       // a component coded twice
+			}
+			seen |= 1u << k;
 		}
-		seen |= 1u << k;
+		const int k = h->Ns == 1 ? h->scan_comp[0] : -2;
 		const size_t end = jh_ecs_end(p, n, h->ecs_offset);
 		if (end >= n) {
 			return RET_FAILURE_FILE_IO;                    // no marker after the data (io.c:197)
@@ -379,7 +387,7 @@ extern "C" int jpeg_hip_decoder_prepare(jpeg_hip_decoder *dec, int nframes,
 	std::vector<std::vector<ScanDesc>> scans(nframes);
 	std::vector<JhQuant> quant(nframes);
 	std::vector<size_t> file_off(nframes);
-	std::vector<int> pass_comp;                            // the batch's scan structure (from the first good frame)
+	std::vector<ScanDesc> pass_comp;                       // the batch's scan structure (from the first good frame)
 	bool have_geom = false;
 	size_t raw_off = 0;
 
@@ -394,13 +402,14 @@ extern "C" int jpeg_hip_decoder_prepare(jpeg_hip_decoder *dec, int nframes,
 				dec->g = h.g;
 				have_geom = true;
 				for (const ScanDesc &sd : scans[f]) {
-					pass_comp.push_back(sd.comp);
+					pass_comp.push_back(sd);
 				}
 			} else {
 				// one batch = one geometry and one scan structure
 				bool same = same_geometry(dec->g, h.g) && scans[f].size() == pass_comp.size();
 				for (size_t i = 0; same && i < pass_comp.size(); ++i) {
-					same = scans[f][i].comp == pass_comp[i];
+					same = scans[f][i].comp == pass_comp[i].comp && scans[f][i].ncs == pass_comp[i].ncs &&
+					       memcmp(scans[f][i].cs, pass_comp[i].cs, sizeof pass_comp[i].cs) == 0;
 				}
 				if (!same) {
 					err = RET_FAILURE_FILE_UNSUPPORTED;
@@ -442,7 +451,9 @@ extern "C" int jpeg_hip_decoder_prepare(jpeg_hip_decoder *dec, int nframes,
 	dec->pass.resize(pass_comp.size());
 	for (size_t pi = 0; pi < pass_comp.size(); ++pi) {
 		DecPass &ps = dec->pass[pi];
-		ps.comp = pass_comp[pi];
+		ps.comp = pass_comp[pi].comp;
+		const int ncs = pass_comp[pi].ncs;
+		const int *cs = pass_comp[pi].cs;
 		ps.g = G;
 		ps.luts.clear();
 		ps.cs_off = ps.seg_off = ps.chunk_off = ps.sub_off = ps.wg_off = 0;
@@ -467,6 +478,22 @@ extern "C" int jpeg_hip_decoder_prepare(jpeg_hip_decoder *dec, int nframes,
 			rm.m_x = G.m_x;
 			rm.B = G.B;
 			rm.kfirst = G.comp_first[k];
+		} else if (ps.comp == -2) {
+			// some of the components: the frame's MCUs with only their blocks, in the scan header's order
+			// (decoder.c:319-358)
+			rm.mode = 2;
+			rm.B = G.B;
+			int nk = 0;
+			for (int j = 0; j < ncs; ++j) {
+				const int k = cs[j];
+				for (int i = 0; i < G.H[k] * G.V[k]; ++i) {
+					ps.g.blk_comp[nk] = (uint8_t)j;            // index of the DC predictor
+					rm.kmap[nk++] = (uint8_t)(G.comp_first[k] + i);
+				}
+			}
+			rm.nk = nk;
+			ps.g.B = nk;
+			ps.g.nblk = G.nmcu * nk;
 		}
 		ps.frames.assign(nframes, JhDecFrame());
 		ps.state.assign(nframes, JhDecState());
@@ -516,9 +543,9 @@ extern "C" int jpeg_hip_decoder_prepare(jpeg_hip_decoder *dec, int nframes,
 			// Huffman tables used by this scan -> LDS slots.  Frames of a Motion JPEG stream mostly share
 			// their tables: a frame whose tables equal the previous frame's reuses its look-up tables.
 			int slot_of[2][4] = {{-1, -1, -1, -1}, {-1, -1, -1, -1}};
-			const int k0 = ps.comp >= 0 ? ps.comp : 0, k1 = ps.comp >= 0 ? ps.comp + 1 : G.ncomp;
 			std::vector<std::pair<int, const JhHuffSpec *>> used;
-			for (int k = k0; k < k1; ++k) {
+			for (int j = 0; j < (ps.comp == -1 ? G.ncomp : ncs); ++j) {
+				const int k = ps.comp == -1 ? j : cs[j];
 				const int ids[2] = {sd.Td[k], sd.Ta[k]};
 				for (int tc = 0; tc < 2; ++tc) {
 					if (slot_of[tc][ids[tc]] < 0) {
@@ -557,7 +584,7 @@ extern "C" int jpeg_hip_decoder_prepare(jpeg_hip_decoder *dec, int nframes,
 				fr.raw_end = fr.raw_begin;
 			}
 			for (int b = 0; b < ps.g.B; ++b) {
-				const int k = ps.comp >= 0 ? ps.comp : G.blk_comp[b];
+				const int k = ps.comp == -1 ? G.blk_comp[b] : cs[ps.g.blk_comp[b]];
 				fr.blk_dc[b] = (uint8_t)slot_of[0][sd.Td[k]];
 				fr.blk_ac[b] = (uint8_t)slot_of[1][sd.Ta[k]];
 			}
@@ -710,7 +737,7 @@ __global__ void k_dec_init(JhDecState *st, int n)
 static int decoder_launch(jpeg_hip_decoder *dec, hipStream_t s)
 {
 	const JhTimerHook th = dec->timer.hook();
-	if (dec->pass.size() > 1 || dec->pass[0].comp >= 0) {
+	if (dec->pass.size() > 1 || dec->pass[0].comp != -1) {
 		// scans of single components: blocks no scan reaches stay zero (common.c:129)
 		if (hipMemsetAsync(dec->d_coefs, 0, (size_t)dec->nframes * dec->g.nblk * 64 * sizeof(int16_t), s) != hipSuccess) {
 			return RET_FAILURE_LOGIC_ERROR;
@@ -773,7 +800,7 @@ extern "C" int jpeg_hip_decoder_sync(jpeg_hip_decoder *dec, int *frame_status)
 				st = RET_FAILURE_FILE_UNSUPPORTED;
 			} else if (ds.term_pos + 1 >= fr.raw_end) {
 				st = RET_FAILURE_FILE_IO;            // no EOI (or a lone FF as the last byte): read_marker() hits end of file (io.c:197)
-			} else if (pi + 1 == dec->pass.size() && dec->pass[pi].comp < 0 && ds.term_marker != 0xd9) {
+			} else if (pi + 1 == dec->pass.size() && dec->pass[pi].comp == -1 && ds.term_marker != 0xd9) {
 				st = RET_FAILURE_FILE_UNSUPPORTED;   // a scan of all components followed by more than EOI: not on the GPU path
 			}
 		}

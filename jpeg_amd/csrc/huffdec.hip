@@ -321,6 +321,10 @@ __device__ __forceinline__ int remap_block(const JhRemap &rm, int n)
 	if (!rm.mode) {
 		return n;
 	}
+	if (rm.mode == 2) {
+		const int m = n / rm.nk;
+		return m * rm.B + rm.kmap[n - m * rm.nk];
+	}
 	// raster position of the component -> (MCU, block of the MCU) of the frame
 	const int by = n / rm.bxc, bx = n - by * rm.bxc;
 	const int my = by / rm.V, mx = bx / rm.H;

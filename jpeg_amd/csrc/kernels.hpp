@@ -51,16 +51,20 @@ struct JhDecState {               // written by the device
 };
 
 // A scan that codes ONE component of a multi-component frame (non-interleaved order, decoder.c:274-302)
-// walks that component's blocks as a raster over its padded grid; the coefficient buffer keeps the
-// interleaved order the pixel kernel reads, so the write pass translates block numbers.
+// walks that component's blocks as a raster over its padded grid; a scan of SOME components
+// (decoder.c:303-358) walks the frame's MCUs but only these components' blocks of each.  The coefficient
+// buffer keeps the interleaved order the pixel kernel reads, so the write pass translates block numbers.
 struct JhRemap {
-	int mode;                     // 0: the scan order IS the buffer order; 1: raster of one component
+	int mode;                     // 0: the scan order IS the buffer order; 1: raster of one component;
+	                              // 2: MCUs of a subset of the components
 	int bxc;                      // blocks per row of the component (b_x)
 	int H, V;                     // its sampling factors
 	int m_x;                      // MCUs per row of the frame
 	int B;                        // blocks per MCU of the frame (buffer order)
 	int kfirst;                   // first block of the component inside an MCU
 	int nblk_full;                // blocks per frame in the buffer
+	int nk;                       // mode 2: blocks per MCU of the scan
+	uint8_t kmap[JH_MAX_MCU_BLOCKS];  // mode 2: block of the scan's MCU -> block of the frame's MCU
 };
 
 struct JhDecodeWork {             // device pointers of one decoder batch

@@ -1528,16 +1528,75 @@ out:
 
 /*
  * EXTENSION (test input generator; the reference encoder writes one interleaved scan only):
- * the image of orc_encode() coded as ONE SCAN PER COMPONENT (A.2.2 non-interleaved order), which the
- * reference DEcoder reads through its Ns == 1 walk (decoder.c:274-302): the blocks of a component in
- * raster order over its padded grid b_x x b_y (quirk Q8), DC prediction along that order, predictors
- * back to 0 at the start of every scan.  restart_interval counts blocks here (an MCU of such a scan is
- * one block).  redefine != 0: every scan names table ids 0/0 and a DHT in front of each scan redefines
- * them (tables "as they stand when the scan starts", decoder.c:581-591).
+ * the image of orc_encode() coded in SEVERAL SCANS, which the reference DEcoder reads scan by scan
+ * (decoder.c:593-601): `split` 0 = one scan per component, 1 = {first} + {the others}, 2 = {all but the
+ * last} + {last}.  A scan of one component follows the reference's Ns == 1 walk (decoder.c:274-302: the
+ * blocks in raster order over the padded grid b_x x b_y, quirk Q8; restart_interval counts blocks there);
+ * a scan of several follows the MCU walk restricted to its components (decoder.c:303-358; the interval
+ * counts MCUs).  DC predictors start at 0 in every scan.  redefine != 0: every scan names table ids 0/0
+ * and a DHT in front of it redefines them (tables "as they stand when the scan starts",
+ * decoder.c:581-591) -- one-component scans only.
  * The judge of these streams is the reference decoder (tests/golden/make_golden.py).
  */
+typedef struct {
+	int n;
+	int comp[ORC_MAXC];
+} scan_set;
+
+/* one scan: statistics (freq != NULL) or bits */
+static int scans_walk(orc_image *img, const scan_set *sc, int ri, sink *s, hufftab *dc, hufftab *ac,
+                      size_t (*freq)[4][257], int td_override, int ta_override)
+{
+	bitw w = {s, 0, 0};
+	int32_t pred[ORC_MAXC] = {0};
+	unsigned rst = 0;
+	size_t units = sc->n == 1 ? img->comp[sc->comp[0]].bx * img->comp[sc->comp[0]].by : img->m_x * img->m_y;
+
+	for (size_t u = 0; u < units; ++u) {
+		if (ri > 0 && u > 0 && u % (size_t)ri == 0) {
+			if (!freq) {
+				bitw_flush(&w);
+				sink_marker(s, 0xd0 + (rst & 7));
+			}
+			rst++;
+			memset(pred, 0, sizeof pred);
+		}
+		for (int j = 0; j < sc->n; ++j) {
+			orc_comp *c = &img->comp[sc->comp[j]];
+			int nv = sc->n == 1 ? 1 : c->V, nh = sc->n == 1 ? 1 : c->H;
+			for (int v = 0; v < nv; ++v) {
+				for (int h = 0; h < nh; ++h) {
+					size_t b = u;
+					if (sc->n > 1) {
+						size_t x = u % img->m_x, y = u / img->m_x;
+						b = (y * (size_t)c->V + (size_t)v) * c->bx + x * (size_t)c->H + (size_t)h;
+					}
+					int32_t blk[64];
+					memcpy(blk, &c->coef[b * 64], sizeof blk);
+					int32_t dcv = blk[0];
+					blk[0] -= pred[j];
+					pred[j] = dcv;
+					if (blk[0] < -2047 || blk[0] > 2047) {
+						return ORC_ERR_DC_RANGE;
+					}
+					int td = td_override >= 0 ? td_override : c->Td, ta = ta_override >= 0 ? ta_override : c->Ta;
+					int err = freq ? code_block(NULL, NULL, NULL, freq[0][c->Td], freq[1][c->Ta], blk)
+					               : code_block(&w, &dc[td], &ac[ta], NULL, NULL, blk);
+					if (err) {
+						return err;
+					}
+				}
+			}
+		}
+	}
+	if (!freq) {
+		bitw_flush(&w);
+	}
+	return ORC_OK;
+}
+
 int orc_encode_scans(const uint8_t *body, int X, int Y, int Nf, int P, int H, int V, int q,
-                     int optimize, int restart_interval, int redefine,
+                     int optimize, int restart_interval, int redefine, int split,
                      uint8_t **jpg, size_t *jpg_len)
 {
 	orc_image *img = NULL;
@@ -1545,6 +1604,8 @@ int orc_encode_scans(const uint8_t *body, int X, int Y, int Nf, int P, int H, in
 	size_t first_len = 0;
 	sink s = {0};
 	hufftab *dc = NULL, *ac = NULL;
+	scan_set scans[ORC_MAXC];
+	int nscans = 0;
 
 	*jpg = NULL;
 	*jpg_len = 0;
@@ -1553,14 +1614,33 @@ int orc_encode_scans(const uint8_t *body, int X, int Y, int Nf, int P, int H, in
 		return err;
 	}
 	free(first);
-	dc = calloc(1, sizeof *dc);
-	ac = calloc(1, sizeof *ac);
+	if (split == 0 || img->ncomp < 3) {
+		for (int k = 0; k < img->ncomp; ++k) {
+			scans[nscans].n = 1;
+			scans[nscans++].comp[0] = k;
+		}
+	} else {
+		int cut = split == 1 ? 1 : img->ncomp - 1;
+		scans[0].n = cut;
+		scans[1].n = img->ncomp - cut;
+		for (int k = 0; k < img->ncomp; ++k) {
+			if (k < cut) {
+				scans[0].comp[k] = k;
+			} else {
+				scans[1].comp[k - cut] = k;
+			}
+		}
+		nscans = 2;
+		redefine = 0;
+	}
+	dc = calloc(4, sizeof *dc);
+	ac = calloc(4, sizeof *ac);
 	if (dc == NULL || ac == NULL) {
 		err = ORC_ERR_MEMORY;
 		goto out;
 	}
 	if (optimize) {
-		/* the DC differences follow the order of THIS walk: statistics and tables again (Annex K.2) */
+		/* the DC differences follow the order of THESE walks: statistics and tables again (Annex K.2) */
 		size_t (*freq)[4][257] = calloc(2, sizeof(size_t[4][257]));
 		if (freq == NULL) {
 			err = ORC_ERR_MEMORY;
@@ -1571,27 +1651,26 @@ int orc_encode_scans(const uint8_t *body, int X, int Y, int Nf, int P, int H, in
 				freq[tc][th][256] = 1;
 			}
 		}
-		for (int k = 0; k < img->ncomp; ++k) {
-			orc_comp *c = &img->comp[k];
-			int32_t pred = 0;
-			for (size_t b = 0; b < c->bx * c->by; ++b) {
-				if (restart_interval > 0 && b > 0 && b % (size_t)restart_interval == 0) {
-					pred = 0;
-				}
-				int32_t blk[64];
-				memcpy(blk, &c->coef[b * 64], sizeof blk);
-				int32_t dcv = blk[0];
-				blk[0] -= pred;
-				pred = dcv;
-				code_block(NULL, NULL, NULL, freq[0][c->Td], freq[1][c->Ta], blk);
-			}
+		for (int i = 0; i < nscans && !err; ++i) {
+			err = scans_walk(img, &scans[i], restart_interval, NULL, NULL, NULL, freq, -1, -1);
 		}
-		for (int tc = 0; tc < 2; ++tc) {
-			for (int th = 0; th < (Nf > 1 ? 2 : 1); ++th) {
-				orc_adapt_table(freq[tc][th], img->htL[tc][th], img->htV[tc][th]);
+		if (!err) {
+			for (int tc = 0; tc < 2; ++tc) {
+				for (int th = 0; th < (Nf > 1 ? 2 : 1); ++th) {
+					orc_adapt_table(freq[tc][th], img->htL[tc][th], img->htV[tc][th]);
+				}
 			}
 		}
 		free(freq);
+		if (err) {
+			goto out;
+		}
+	}
+	for (int th = 0; th < 2; ++th) {
+		hufftab_build(&dc[th], img->htL[0][th], img->htV[0][th]);
+		orc_make_codes(img->htL[0][th], img->htV[0][th], dc[th].ehufsi, dc[th].ehufco);
+		hufftab_build(&ac[th], img->htL[1][th], img->htV[1][th]);
+		orc_make_codes(img->htL[1][th], img->htV[1][th], ac[th].ehufsi, ac[th].ehufco);
 	}
 	sink_marker(&s, 0xd8);
 	for (int t = 0; t < (Nf > 1 ? 2 : 1); ++t) {
@@ -1624,52 +1703,32 @@ int orc_encode_scans(const uint8_t *body, int X, int Y, int Nf, int P, int H, in
 		sink_word(&s, 4);
 		sink_word(&s, (unsigned)restart_interval);
 	}
-	for (int k = 0; k < img->ncomp; ++k) {
-		orc_comp *c = &img->comp[k];
-		int td = c->Td, ta = c->Ta;
-		hufftab_build(dc, img->htL[0][td], img->htV[0][td]);
-		orc_make_codes(img->htL[0][td], img->htV[0][td], dc->ehufsi, dc->ehufco);
-		hufftab_build(ac, img->htL[1][ta], img->htV[1][ta]);
-		orc_make_codes(img->htL[1][ta], img->htV[1][ta], ac->ehufsi, ac->ehufco);
-		if (redefine) {
-			put_dht(&s, 0, 0, img->htL[0][td], img->htV[0][td]);
-			put_dht(&s, 1, 0, img->htL[1][ta], img->htV[1][ta]);
-			td = ta = 0;
+	for (int i = 0; i < nscans; ++i) {
+		const scan_set *sc = &scans[i];
+		int tdo = -1, tao = -1;
+		if (redefine) {                                          /* one component: its tables under ids 0/0 */
+			orc_comp *c = &img->comp[sc->comp[0]];
+			put_dht(&s, 0, 0, img->htL[0][c->Td], img->htV[0][c->Td]);
+			put_dht(&s, 1, 0, img->htL[1][c->Ta], img->htV[1][c->Ta]);
+			dc[2] = dc[c->Td];
+			ac[2] = ac[c->Ta];
+			tdo = tao = 2;                                       /* the codes of the table that now sits under id 0 */
 		}
 		sink_marker(&s, 0xda);
-		sink_word(&s, 8);
-		sink_put(&s, 1);
-		sink_put(&s, (uint8_t)c->id);
-		sink_put(&s, (uint8_t)((td << 4) | ta));
+		sink_word(&s, 6u + 2u * (unsigned)sc->n);
+		sink_put(&s, (uint8_t)sc->n);
+		for (int j = 0; j < sc->n; ++j) {
+			orc_comp *c = &img->comp[sc->comp[j]];
+			sink_put(&s, (uint8_t)c->id);
+			sink_put(&s, (uint8_t)(redefine ? 0 : ((c->Td << 4) | c->Ta)));
+		}
 		sink_put(&s, 0);
 		sink_put(&s, 63);
 		sink_put(&s, 0);
-		bitw w = {&s, 0, 0};
-		int32_t pred = 0;
-		unsigned rst = 0;
-		size_t total = c->bx * c->by;
-		for (size_t b = 0; b < total; ++b) {
-			if (restart_interval > 0 && b > 0 && b % (size_t)restart_interval == 0) {
-				bitw_flush(&w);
-				sink_marker(&s, 0xd0 + (rst & 7));
-				rst++;
-				pred = 0;
-			}
-			int32_t blk[64];
-			memcpy(blk, &c->coef[b * 64], sizeof blk);
-			int32_t dcv = blk[0];
-			blk[0] -= pred;
-			pred = dcv;
-			if (blk[0] < -2047 || blk[0] > 2047) {
-				err = ORC_ERR_DC_RANGE;
-				goto out;
-			}
-			err = code_block(&w, dc, ac, NULL, NULL, blk);
-			if (err) {
-				goto out;
-			}
+		err = scans_walk(img, sc, restart_interval, &s, dc, ac, NULL, tdo, tao);
+		if (err) {
+			goto out;
 		}
-		bitw_flush(&w);
 	}
 	sink_marker(&s, 0xd9);
 	if (s.oom) {

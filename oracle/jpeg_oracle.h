@@ -63,11 +63,13 @@ int orc_encode(const uint8_t *body, int X, int Y, int Nf, int P, int H, int V, i
                int optimize, int restart_interval,
                orc_image **img, uint8_t **jpg, size_t *jpg_len);
 
-/* EXTENSION, test input generator: the same image as one scan per component (non-interleaved order,
- * what the reference decoder's Ns == 1 walk reads, decoder.c:274-302); restart_interval in blocks;
- * redefine != 0 re-sends the Huffman tables under ids 0/0 in front of every scan. */
+/* EXTENSION, test input generator: the same image in several scans (what the reference decoder reads scan
+ * by scan, decoder.c:593-601).  split 0: one scan per component (Ns == 1 walk, decoder.c:274-302;
+ * restart_interval in blocks), 1: {first} + {others}, 2: {all but last} + {last} (MCU walk restricted to the
+ * scan's components, interval in MCUs); redefine != 0 (split 0) re-sends the Huffman tables under ids 0/0 in
+ * front of every scan. */
 int orc_encode_scans(const uint8_t *body, int X, int Y, int Nf, int P, int H, int V, int q,
-                     int optimize, int restart_interval, int redefine,
+                     int optimize, int restart_interval, int redefine, int split,
                      uint8_t **jpg, size_t *jpg_len);
 
 void orc_image_free(orc_image *img);

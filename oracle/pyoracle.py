@@ -80,7 +80,7 @@ class Oracle:
         self.L = L
         L.orc_decode.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(_u8p), C.POINTER(C.c_size_t)]
         L.orc_encode.argtypes = [C.c_char_p] + [C.c_int] * 9 + [C.POINTER(C.c_void_p), C.POINTER(_u8p), C.POINTER(C.c_size_t)]
-        L.orc_encode_scans.argtypes = [C.c_char_p] + [C.c_int] * 10 + [C.POINTER(_u8p), C.POINTER(C.c_size_t)]
+        L.orc_encode_scans.argtypes = [C.c_char_p] + [C.c_int] * 11 + [C.POINTER(_u8p), C.POINTER(C.c_size_t)]
         L.orc_image_free.argtypes = [C.c_void_p]
         L.orc_free.argtypes = [C.c_void_p]
         L.orc_img_info.argtypes = [C.c_void_p] + [C.POINTER(C.c_int)] * 5 + [C.POINTER(C.c_size_t)] * 5
@@ -164,14 +164,14 @@ class Oracle:
         self.L.orc_image_free(h)
         return 0, jpg, img
 
-    def encode_scans(self, samples, P=8, H=2, V=1, q=75, optimize=1, restart_interval=0, redefine=0):
+    def encode_scans(self, samples, P=8, H=2, V=1, q=75, optimize=1, restart_interval=0, redefine=0, split=0):
         """EXTENSION: the image as one scan per component (decoder test input) -> (err, jpeg bytes)."""
         a = np.asarray(samples)
         Y, X = a.shape[:2]
         Nf = 1 if a.ndim == 2 else a.shape[2]
         out = _u8p()
         n = C.c_size_t()
-        err = self.L.orc_encode_scans(pnm_body(a, P), X, Y, Nf, P, H, V, q, optimize, restart_interval, redefine,
+        err = self.L.orc_encode_scans(pnm_body(a, P), X, Y, Nf, P, H, V, q, optimize, restart_interval, redefine, split,
                                       C.byref(out), C.byref(n))
         if err:
             return err, None

@@ -122,16 +122,20 @@ def main():
 
     # one scan per component (non-interleaved order, decoder.c:274-302): written by the oracle's extension
     # writer, judged by the reference decoder like every other input here
-    for name, (X, Y, H, V, q, opt, ri, redef, seed) in {
+    # and scans of SOME components (decoder.c:303-358 with Ns < Nf): split 1 = {Y} {Cb Cr}, 2 = {Y Cb} {Cr}
+    for name, (X, Y, H, V, q, opt, ri, redef, seed, *split) in {
         "d_scans_420_opt": (80, 64, 2, 2, 80, 1, 0, 0, 51),
         "d_scans_444_rst7": (64, 48, 1, 1, 90, 0, 7, 0, 52),
         "d_scans_422_redefine": (96, 40, 2, 1, 70, 1, 0, 1, 53),
         "d_scans_420_unaligned_rst8": (100, 75, 2, 2, 80, 1, 8, 1, 54),
         # an interval that ends inside the reference's H x V block group: bug-compatible, not standard
         "d_scans_420_rst5_quirk": (100, 75, 2, 2, 80, 1, 5, 0, 55),
+        "d_scans_420_y_cbcr": (80, 64, 2, 2, 80, 1, 0, 0, 56, 1),
+        "d_scans_422_ycb_cr_rst3": (100, 75, 2, 1, 85, 0, 3, 0, 57, 2),
+        "d_scans_420_ycb_cr_rst4_opt": (100, 75, 2, 2, 75, 1, 4, 0, 58, 2),
     }.items():
         err, data = orc.encode_scans(synth_image(X, Y, 3, 8, seed, False), P=8, H=H, V=V, q=q, optimize=opt,
-                                     restart_interval=ri, redefine=redef)
+                                     restart_interval=ri, redefine=redef, split=split[0] if split else 0)
         assert err == 0, (name, err)
         dec_inputs[name] = data
 

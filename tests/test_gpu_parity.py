@@ -285,6 +285,40 @@ def test_intervals_that_end_inside_an_mcu(hip, oracle, sync_debug):
     d.close()
 
 
+@pytest.mark.parametrize("split", [0, 1, 2])
+def test_frames_coded_in_several_scans(hip, oracle, split):
+    """Scans of one component (decoder.c:274-302) and of some of the components (decoder.c:303-358 with
+    Ns < Nf), written by the oracle's extension writer (judged by the reference decoder in
+    tests/golden/make_golden.py and test_oracle_vs_ref): a batch large enough for several workgroups per
+    scan, with and without restart intervals, on every synchronisation path."""
+    imgs = [synth_image(416, 272, 3, 8, seed=90 + i, frame=i) for i in range(3)]
+    for (H, V, ri, opt) in [(2, 2, 0, 1), (2, 1, 5, 0), (1, 1, 8, 1), (1, 2, 3, 1)]:
+        jpgs = []
+        for im in imgs:
+            err, j = oracle.encode_scans(im, P=8, H=H, V=V, q=88, optimize=opt, restart_interval=ri, split=split)
+            assert err == 0
+            jpgs.append(j)
+        for dbg in (0, 1, 2):
+            d = hip.Decoder()
+            d.set_debug(dbg)
+            d.prepare(jpgs)
+            out = d.run()
+            assert d.sync() == [0] * len(jpgs)
+            arrs = d.to_arrays(out)
+            for i, j in enumerate(jpgs):
+                err, opx, oinfo = oracle.decode(j)
+                assert err == 0
+                _assert_coefs(d.coefficients(i), oinfo)
+                assert np.array_equal(arrs[i], opx)
+            d.close()
+    # frames of one batch must share the scan structure
+    a = oracle.encode_scans(imgs[0], P=8, H=2, V=2, q=80, split=split)[1]
+    b = oracle.encode_scans(imgs[1], P=8, H=2, V=2, q=80, split=(split + 1) % 3)[1]
+    outs, st = hip.decode([a, b])
+    assert st == [0, 0x1001]                              # RET_FAILURE_FILE_UNSUPPORTED for the odd one out
+    assert np.array_equal(outs[0], oracle.decode(a)[1])
+
+
 def test_motion_jpeg_stream_in_batches(hip, oracle):
     """A concatenated stream (incl. DHT-less frames that rely on the implicit tables, common.c:90-99)
     is split by the C++ splitter and decoded in batches; every frame equals the oracle's decode."""

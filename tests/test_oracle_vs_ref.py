@@ -100,6 +100,27 @@ def test_restart_extension_decodes_identically_with_reference(oracle, reference)
         assert eo == 0 and np.array_equal(so, sr)
 
 
+def test_several_scans_decode_identically_with_reference(oracle, reference):
+    """Frames coded in several scans are written by the oracle's extension writer (the reference encoder
+    writes one scan).  The reference DECODER is the judge: same samples and coefficients as from the
+    one-scan stream where the intervals respect its block groups, and the oracle's decoder agrees with it
+    on every stream, the bug-compatible ones included (interval inside the H x V block group)."""
+    img = synth_image(104, 72, 3, 8, seed=6)
+    for split in (0, 1, 2):
+        for (H, V, ri, opt, redefine) in [(2, 2, 0, 1, 0), (2, 1, 4, 0, 1), (1, 1, 7, 1, 0), (2, 2, 5, 1, 1), (1, 2, 2, 0, 0)]:
+            e0, j0, _ = oracle.encode(img, P=8, H=H, V=V, q=85, optimize=opt)
+            e1, j1 = oracle.encode_scans(img, P=8, H=H, V=V, q=85, optimize=opt, restart_interval=ri,
+                                         redefine=redefine, split=split)
+            assert e0 == 0 and e1 == 0
+            er, sr, dr = reference.decode(j1)
+            eo, so, do = oracle.decode(j1)
+            assert er == 0 and eo == 0
+            assert np.array_equal(so, sr) and _same_coefs(do, dr)
+            if ri % (H * V) == 0:
+                e0r, s0r, d0r = reference.decode(j0)
+                assert e0r == 0 and np.array_equal(sr, s0r) and _same_coefs(dr, d0r)
+
+
 def test_truncated_and_garbage_streams_agree(oracle, reference):
     img = synth_image(64, 48, 3, 8, seed=9)
     _, jpg, _ = reference.encode(img, P=8, H=2, V=2, q=80, optimize=1)

@@ -72,8 +72,9 @@ for case in range(N):
     # ---- decode, one scan per component
     if nc == 3 and P == 8:
         blocks = H * V
-        rib = rnd.choice([0, blocks * rnd.randint(1, 9)])
-        err, sj = orc.encode_scans(imgs[0], P=P, H=H, V=V, q=q, optimize=opt, restart_interval=rib, redefine=rnd.randint(0, 1))
+        split = rnd.randint(0, 2)                       # one scan per component, {Y}{Cb Cr}, {Y Cb}{Cr}
+        rib = rnd.choice([0, blocks * rnd.randint(1, 9), rnd.randint(1, 11)])
+        err, sj = orc.encode_scans(imgs[0], P=P, H=H, V=V, q=q, optimize=opt, restart_interval=rib, redefine=rnd.randint(0, 1), split=split)
         if err == 0:
             oerr, opx, oinfo = orc.decode(sj)
             d = binding.Decoder()
@@ -81,7 +82,7 @@ for case in range(N):
             out = d.run()
             stt = d.sync()
             if stt[0] != oerr or not np.array_equal(d.to_arrays(out)[0], opx):
-                print("DECODE SCANS", desc, rib, stt[0], oerr); bad += 1
+                print("DECODE SCANS", desc, rib, split, stt[0], oerr); bad += 1
             d.close()
     if case % 20 == 19:
         print("... %d cases, %d mismatches, %d without a valid stream, %.0f s" % (case + 1, bad, skipped, time.time() - t0), flush=True)
