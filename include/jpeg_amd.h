@@ -168,6 +168,67 @@ int  jpeg_hip_encoder_get_coefficients(jpeg_hip_encoder *enc, int frame, int k, 
 void jpeg_hip_encoder_set_timing(jpeg_hip_encoder *enc, int on);
 int  jpeg_hip_encoder_get_timing(jpeg_hip_encoder *enc, const char **names, float *ms, int cap);
 
+/* ---- stage level: the four hot loops, one call each, on what `struct context` holds ------------
+ * For a maintainer who keeps the reference's own marker parser and producer (parse_format()
+ * decoder.c:472-659, produce_codestream() encoder.c:589-645) and swaps only the loops (SURVEY.md
+ * section 8b).  One frame per call, HOST pointers in and out, synchronous; the arrays are the members of
+ * `struct context` flattened (common.h:52-113): sampling factors and table selectors per component in
+ * frame order, quantisation tables in raster order as qtable[].Q, Huffman tables as the DHT payload
+ * (BITS, HUFFVAL), coefficients as component[].int_buffer (b_y*b_x blocks of 64 int32, raster order
+ * inside a block).  These calls pay an upload and a download each: the batch objects above are the
+ * fast path, these are the drop-in and the stage-parity path. */
+typedef struct jpeg_hip_frame_desc {
+	int X, Y, P, Nf;                          /* context->X, Y, precision, Nf */
+	int H[JPEG_HIP_MAX_COMP], V[JPEG_HIP_MAX_COMP], Tq[JPEG_HIP_MAX_COMP];   /* component[].H, V, Tq */
+} jpeg_hip_frame_desc;
+
+typedef struct jpeg_hip_htable {              /* struct htable, common.h:85-91 */
+	uint8_t L[16];                            /* codes of each length 1..16 */
+	uint8_t V[256];                           /* symbols in code order */
+} jpeg_hip_htable;
+
+typedef struct jpeg_hip_scan_desc {           /* struct scan, decoder.c:186-195, encoder.c:318-327 */
+	int Ns;                                   /* components in the scan */
+	int Cs[JPEG_HIP_MAX_COMP];                /* their indices in the frame (0-based, frame order), scan header order */
+	int Td[JPEG_HIP_MAX_COMP], Ta[JPEG_HIP_MAX_COMP];   /* table selectors of the j-th scan component
+	                                             (component[Cs].Td / Ta, parse_scan_header() decoder.c:197-259) */
+	int restart_interval;                     /* read: context->Ri (sizes the workspace only; as in the reference
+	                                             the markers decide).  write: EXTENSION, MCUs per interval, 0 = none */
+} jpeg_hip_scan_desc;
+
+/* read_ecs(stream, context, scan), decoder.c:364-388 with its callees: decodes the entropy-coded data of
+ * ONE scan.  ecs[0 .. n) starts behind the SOS header and must reach at least the marker that ends the
+ * scan (else RET_FAILURE_FILE_IO, as read_marker() at end of file).  dc[]/ac[] = context->htable[0/1][0..3]
+ * as they stand when the scan starts.  coef[k] (components of the scan only) receive the coefficients with
+ * DC prediction undone (decoder.c:351-355); blocks the data does not reach are zero (common.c:129).
+ * *consumed = offset of the marker that ended the scan (where read_ecs_byte() leaves the stream, io.c:265). */
+int jpeg_hip_read_scan(int device, const jpeg_hip_frame_desc *frame, const jpeg_hip_scan_desc *scan,
+                       const jpeg_hip_htable dc[4], const jpeg_hip_htable ac[4],
+                       const uint8_t *ecs, size_t n, int32_t *const coef[JPEG_HIP_MAX_COMP], size_t *consumed);
+
+/* epilogue(context, path) without the file, decoder.c:456-470: dequantize, inverse_dct,
+ * conv_blocks_to_frame, frame_create, frame_to_rgb, write_frame_body.  Q = context->qtable[0..3].Q.
+ * samples receives the PPM/PGM body: Y*X*(1 or 3) samples, u8 or big-endian u16 (P > 8). */
+int jpeg_hip_decode_pixels(int device, const jpeg_hip_frame_desc *frame, const uint16_t Q[4][64],
+                           const int32_t *const coef[JPEG_HIP_MAX_COMP], void *samples);
+
+/* prologue(context, stream, params) behind read_frame_header(), encoder.c:176-193: read_frame_body,
+ * frame_to_ycc, transform_frame_to_components, conv_frame_to_blocks, forward_dct, quantize.  The frame
+ * must be one the reference encoder sets up (encoder.c:109-146: one component, or three with chroma 1x1,
+ * luma H, V in 1..2, Tq 0 / 1 / 1); otherwise RET_FAILURE_FILE_UNSUPPORTED. */
+int jpeg_hip_encode_pixels(int device, const jpeg_hip_frame_desc *frame, const uint16_t Q[4][64],
+                           const void *samples, int32_t *const coef[JPEG_HIP_MAX_COMP]);
+
+/* write_ecs_dry() + adapt_huffman_table() + write_ecs(), encoder.c:525-587, huffman.c:508-537: the
+ * entropy-coded data of the frame's one interleaved scan (all components, table selectors 0 / 1 / 1 as the
+ * reference encoder uses them), byte-stuffed and padded, WITHOUT the EOI marker.  optimize == 0: codes from
+ * dc[0..1] / ac[0..1]; optimize != 0: the tables are derived from the coefficients (Annex K.2) and
+ * RETURNED in dc[] / ac[] for the caller's DHT segments.  Returns JPEG_HIP_ERR_DC_RANGE / _NO_CODE where the
+ * reference asserts / fails, RET_FAILURE_OVERFLOW_ERROR when cap is too small (*n = bytes needed). */
+int jpeg_hip_write_scan(int device, const jpeg_hip_frame_desc *frame, const jpeg_hip_scan_desc *scan,
+                        jpeg_hip_htable dc[4], jpeg_hip_htable ac[4], int optimize,
+                        const int32_t *const coef[JPEG_HIP_MAX_COMP], uint8_t *out, size_t cap, size_t *n);
+
 /* ---- single-image drop-ins for the reference's top-level entry points ------------------------
  * Same argument meaning and error behaviour as the functions they replace; the pixel and entropy
  * work runs on the GPU, marker parsing/production and PPM/PGM I/O on the host. */

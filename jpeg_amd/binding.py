@@ -36,6 +36,7 @@ EXPORTS = [
     "jpeg_hip_encoder_get_jpeg", "jpeg_hip_encoder_device_jpeg", "jpeg_hip_encoder_get_coefficients",
     "jpeg_hip_encoder_set_timing", "jpeg_hip_encoder_get_timing",
     "jpeg_hip_process_jpeg_stream", "jpeg_hip_process_jpeg_file", "jpeg_hip_process_stream",
+    "jpeg_hip_read_scan", "jpeg_hip_decode_pixels", "jpeg_hip_encode_pixels", "jpeg_hip_write_scan",
 ]
 
 
@@ -54,6 +55,23 @@ class FrameInfo(C.Structure):
 class Params(C.Structure):
     """struct params of the reference (encoder.c:68-76) + the restart-interval extension."""
     _fields_ = [("H", C.c_uint8), ("V", C.c_uint8), ("q", C.c_int), ("optimize", C.c_int),
+                ("restart_interval", C.c_int)]
+
+
+class FrameDesc(C.Structure):
+    """jpeg_hip_frame_desc: what `struct context` knows about the frame (common.h:124-156)."""
+    _fields_ = [("X", C.c_int), ("Y", C.c_int), ("P", C.c_int), ("Nf", C.c_int),
+                ("H", C.c_int * MAX_COMP), ("V", C.c_int * MAX_COMP), ("Tq", C.c_int * MAX_COMP)]
+
+
+class HTable(C.Structure):
+    """jpeg_hip_htable: BITS and HUFFVAL of one DHT table (struct htable, common.h:85-91)."""
+    _fields_ = [("L", C.c_uint8 * 16), ("V", C.c_uint8 * 256)]
+
+
+class ScanDesc(C.Structure):
+    """jpeg_hip_scan_desc (struct scan, decoder.c:186-195)."""
+    _fields_ = [("Ns", C.c_int), ("Cs", C.c_int * MAX_COMP), ("Td", C.c_int * MAX_COMP), ("Ta", C.c_int * MAX_COMP),
                 ("restart_interval", C.c_int)]
 
 
@@ -117,6 +135,11 @@ def lib():
         L.jpeg_hip_encoder_set_timing.restype = None
         L.jpeg_hip_encoder_get_timing.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int]
         L.jpeg_hip_process_jpeg_file.argtypes = [C.c_char_p, C.c_char_p]
+        fdp, sdp, htp, cpp = C.POINTER(FrameDesc), C.POINTER(ScanDesc), C.POINTER(HTable), C.POINTER(vp)
+        L.jpeg_hip_read_scan.argtypes = [C.c_int, fdp, sdp, htp, htp, C.c_char_p, sz, cpp, C.POINTER(sz)]
+        L.jpeg_hip_decode_pixels.argtypes = [C.c_int, fdp, vp, cpp, vp]
+        L.jpeg_hip_encode_pixels.argtypes = [C.c_int, fdp, vp, vp, cpp]
+        L.jpeg_hip_write_scan.argtypes = [C.c_int, fdp, sdp, htp, htp, C.c_int, cpp, vp, sz, C.POINTER(sz)]
         _lib = L
     return _lib
 
@@ -357,3 +380,100 @@ def encode(images, P=8, H=2, V=1, q=75, optimize=1, device=0, restart_interval=0
         return [e.jpeg(f, ln[f]) if st[f] == 0 else None for f in range(len(images))], st
     finally:
         e.close()
+
+
+# ---- stage level (jpeg_hip_read_scan / decode_pixels / encode_pixels / write_scan) -------------------------
+# Thin ctypes wrappers on host numpy arrays: what a maintainer calls from inside the reference's own
+# parse_format() / produce_codestream(), and what the stage-parity tests call.
+
+def frame_desc(X, Y, P, H, V, Tq):
+    fd = FrameDesc()
+    fd.X, fd.Y, fd.P, fd.Nf = X, Y, P, len(H)
+    for k in range(len(H)):
+        fd.H[k], fd.V[k], fd.Tq[k] = H[k], V[k], Tq[k]
+    return fd
+
+
+def scan_desc(Cs, Td, Ta, restart_interval=0):
+    sd = ScanDesc()
+    sd.Ns = len(Cs)
+    for j in range(len(Cs)):
+        sd.Cs[j], sd.Td[j], sd.Ta[j] = Cs[j], Td[j], Ta[j]
+    sd.restart_interval = restart_interval
+    return sd
+
+
+def htables(tabs):
+    """tabs: up to four (L[16], V[...]) pairs or None -> HTable[4]."""
+    arr = (HTable * 4)()
+    for i, t in enumerate(tabs):
+        if t is None:
+            continue
+        Lc, Vs = t
+        for j in range(16):
+            arr[i].L[j] = int(Lc[j])
+        for j, v in enumerate(Vs):
+            arr[i].V[j] = int(v)
+    return arr
+
+
+def _blocks(fd, k):
+    """(b_y, b_x) of component k (common.c:171-182; one-component frames: the padded grid of that component)."""
+    Nf = fd.Nf
+    mh = max(fd.H[i] for i in range(Nf))
+    mv = max(fd.V[i] for i in range(Nf))
+    m_x = (fd.X + 8 * mh - 1) // (8 * mh)
+    m_y = (fd.Y + 8 * mv - 1) // (8 * mv)
+    return m_y * fd.V[k], m_x * fd.H[k]
+
+
+def _coef_ptrs(arrs):
+    ptrs = (C.c_void_p * MAX_COMP)()
+    for k, a in enumerate(arrs):
+        ptrs[k] = a.ctypes.data if a is not None else None
+    return ptrs
+
+
+def read_scan(fd, sd, dc, ac, ecs, device=0):
+    """-> (RET code, {component: int32 [b_y*b_x, 64]}, offset of the marker that ended the scan)."""
+    coefs = [None] * MAX_COMP
+    for j in range(sd.Ns):
+        by, bx = _blocks(fd, sd.Cs[j])
+        coefs[sd.Cs[j]] = np.zeros((by * bx, 64), np.int32)
+    used = C.c_size_t(0)
+    err = lib().jpeg_hip_read_scan(device, C.byref(fd), C.byref(sd), dc, ac, ecs, len(ecs), _coef_ptrs(coefs), C.byref(used))
+    return err, {sd.Cs[j]: coefs[sd.Cs[j]] for j in range(sd.Ns)}, used.value
+
+
+def decode_pixels(fd, Q, coefs, device=0):
+    """Q: uint16 [4, 64] raster order; coefs: list of int32 arrays per component -> (RET code, samples)."""
+    Q = np.ascontiguousarray(Q, np.uint16)
+    coefs = [np.ascontiguousarray(c, np.int32) for c in coefs]
+    nc = 1 if fd.Nf == 1 else 3
+    shape = (fd.Y, fd.X) if nc == 1 else (fd.Y, fd.X, 3)
+    out = np.zeros(shape, np.uint8 if fd.P <= 8 else ">u2")
+    err = lib().jpeg_hip_decode_pixels(device, C.byref(fd), Q.ctypes.data, _coef_ptrs(coefs), out.ctypes.data)
+    return err, out.astype(np.uint8 if fd.P <= 8 else np.uint16)
+
+
+def encode_pixels(fd, Q, samples, device=0):
+    """samples: [Y, X] or [Y, X, 3] -> (RET code, list of int32 [b_y*b_x, 64] per component)."""
+    Q = np.ascontiguousarray(Q, np.uint16)
+    body = np.ascontiguousarray(samples, np.uint8 if fd.P <= 8 else ">u2")
+    coefs = []
+    for k in range(fd.Nf):
+        by, bx = _blocks(fd, k)
+        coefs.append(np.zeros((by * bx, 64), np.int32))
+    err = lib().jpeg_hip_encode_pixels(device, C.byref(fd), Q.ctypes.data, body.ctypes.data, _coef_ptrs(coefs))
+    return err, coefs
+
+
+def write_scan(fd, sd, dc, ac, optimize, coefs, device=0):
+    """-> (RET code, entropy-coded bytes); with optimize the tables come back in dc / ac."""
+    coefs = [np.ascontiguousarray(c, np.int32) for c in coefs]
+    cap = 4096 + sum(c.size for c in coefs) * 4
+    out = np.zeros(cap, np.uint8)
+    n = C.c_size_t(0)
+    err = lib().jpeg_hip_write_scan(device, C.byref(fd), C.byref(sd), dc, ac, int(optimize), _coef_ptrs(coefs),
+                                    out.ctypes.data, cap, C.byref(n))
+    return err, out[:n.value].tobytes() if err == 0 else b""

@@ -14,6 +14,7 @@
 #include <utility>
 #include <chrono>
 #include <string>
+#include <functional>
 #include "../../include/jpeg_amd.h"
 #include "common.hpp"
 #include "codestream.hpp"
@@ -206,6 +207,7 @@ struct jpeg_hip_decoder {
 	bool ran = false;
 	int debug = 0;
 	bool tolerant = false;
+	bool coefs_only = false;          // run() stops behind the Huffman passes (jpeg_hip_read_scan)
 	StageTimer timer;
 
 	// Device buffers only grow: a decoder that is prepared again with a batch of similar size (Motion
@@ -360,8 +362,11 @@ static int parse_frame(const uint8_t *p, size_t n, JhHeader *h, std::vector<Scan
 	return RET_SUCCESS;
 }
 
-extern "C" int jpeg_hip_decoder_prepare(jpeg_hip_decoder *dec, int nframes,
-                                        const uint8_t *const *jpg, const size_t *jpg_len)
+// headers and scans of frame f: parse_frame() for codestreams, or the caller's description (jpeg_hip_read_scan)
+typedef std::function<int(int, JhHeader *, std::vector<ScanDesc> *)> FrameParser;
+
+static int decoder_prepare(jpeg_hip_decoder *dec, int nframes, const uint8_t *const *jpg, const size_t *jpg_len,
+                           const FrameParser &parse)
 {
 	if (!dec || nframes <= 0) {
 		return RET_FAILURE_LOGIC_ERROR;
@@ -393,7 +398,7 @@ extern "C" int jpeg_hip_decoder_prepare(jpeg_hip_decoder *dec, int nframes,
 
 	for (int f = 0; f < nframes; ++f) {
 		JhHeader &h = hdr[f];
-		int err = parse_frame(jpg[f], jpg_len[f], &h, &scans[f], dec->tolerant);
+		int err = parse(f, &h, &scans[f]);
 		if (!err) {
 			err = jh_finish_geometry(&h.g);
 		}
@@ -708,6 +713,17 @@ extern "C" int jpeg_hip_decoder_prepare(jpeg_hip_decoder *dec, int nframes,
 	return RET_SUCCESS;
 }
 
+extern "C" int jpeg_hip_decoder_prepare(jpeg_hip_decoder *dec, int nframes,
+                                        const uint8_t *const *jpg, const size_t *jpg_len)
+{
+	if (!dec || nframes <= 0 || !jpg || !jpg_len) {
+		return RET_FAILURE_LOGIC_ERROR;
+	}
+	return decoder_prepare(dec, nframes, jpg, jpg_len, [&](int f, JhHeader *h, std::vector<ScanDesc> *sc) {
+		return parse_frame(jpg[f], jpg_len[f], h, sc, dec->tolerant);
+	});
+}
+
 extern "C" int jpeg_hip_decoder_info(const jpeg_hip_decoder *dec, jpeg_hip_frame_info *info)
 {
 	if (!dec || dec->nframes == 0) {
@@ -751,6 +767,9 @@ static int decoder_launch(jpeg_hip_decoder *dec, hipStream_t s)
 		if (jh_launch_huff_decode(ps.work, ps.g, s, &th)) {
 			return RET_FAILURE_LOGIC_ERROR;
 		}
+	}
+	if (dec->coefs_only) {
+		return RET_SUCCESS;                                // jpeg_hip_read_scan: the coefficients are the result
 	}
 	dec->timer.begin("k_decode_pixels", s);
 	if (jh_launch_decode_pixels(dec->g, dec->nframes, dec->d_coefs, dec->d_quant, dec->last_out, dec->last_stride, s)) {
@@ -800,7 +819,7 @@ extern "C" int jpeg_hip_decoder_sync(jpeg_hip_decoder *dec, int *frame_status)
 				st = RET_FAILURE_FILE_UNSUPPORTED;
 			} else if (ds.term_pos + 1 >= fr.raw_end) {
 				st = RET_FAILURE_FILE_IO;            // no EOI (or a lone FF as the last byte): read_marker() hits end of file (io.c:197)
-			} else if (pi + 1 == dec->pass.size() && dec->pass[pi].comp == -1 && ds.term_marker != 0xd9) {
+			} else if (pi + 1 == dec->pass.size() && dec->pass[pi].comp == -1 && ds.term_marker != 0xd9 && !dec->coefs_only) {
 				st = RET_FAILURE_FILE_UNSUPPORTED;   // a scan of all components followed by more than EOI: not on the GPU path
 			}
 		}
@@ -964,8 +983,9 @@ static int upload_codes_and_headers(jpeg_hip_encoder *e, int f0, int f1, hipStre
 	return RET_SUCCESS;
 }
 
-extern "C" int jpeg_hip_encoder_configure(jpeg_hip_encoder *enc, int nframes, int X, int Y, int Nf, int P,
-                                          const jpeg_hip_params *params)
+// Q / ht: tables of the caller instead of the quality-scaled and the default ones (stage level API)
+static int encoder_configure(jpeg_hip_encoder *enc, int nframes, int X, int Y, int Nf, int P,
+                             const jpeg_hip_params *params, const uint16_t (*Q)[64], const JhHuffSpec (*ht)[4])
 {
 	if (!enc || !params || nframes <= 0) {
 		return RET_FAILURE_LOGIC_ERROR;
@@ -1011,6 +1031,12 @@ extern "C" int jpeg_hip_encoder_configure(jpeg_hip_encoder *enc, int nframes, in
 		for (int th = 0; th < 4; ++th) {
 			jh_default_table(tc, th & 1, &enc->ht[tc][th]);
 		}
+	}
+	if (Q) {
+		memcpy(enc->Q, Q, sizeof enc->Q);
+	}
+	if (ht) {
+		memcpy(enc->ht, ht, sizeof enc->ht);
 	}
 
 	JhEncodeWork &w = enc->work;
@@ -1095,6 +1121,12 @@ extern "C" int jpeg_hip_encoder_configure(jpeg_hip_encoder *enc, int nframes, in
 	enc->state.assign(nframes, JhEncState());
 	// default tables + headers for every frame (the optimised path overwrites them per run)
 	return upload_codes_and_headers(enc, 0, nframes, nullptr);
+}
+
+extern "C" int jpeg_hip_encoder_configure(jpeg_hip_encoder *enc, int nframes, int X, int Y, int Nf, int P,
+                                          const jpeg_hip_params *params)
+{
+	return encoder_configure(enc, nframes, X, Y, Nf, P, params, nullptr, nullptr);
 }
 
 extern "C" int jpeg_hip_encoder_info(const jpeg_hip_encoder *enc, jpeg_hip_frame_info *info)
@@ -1225,6 +1257,384 @@ extern "C" int jpeg_hip_encoder_get_timing(jpeg_hip_encoder *enc, const char **n
 }
 
 // ======================================================================================= single-image drop-ins
+
+// ---- stage level: the four hot loops on flattened `struct context` members (jpeg_amd.h) --------------
+
+// the reference's int_buffer layout of component k -> scan-order / zig-zag int16 coefficients of one frame
+static bool reference_layout_to_coefs(const JhGeom &g, int k, const int32_t *in, int16_t *fc)
+{
+	bool fits = true;
+	for (int by = 0; by < g.by[k]; ++by) {
+		for (int bx = 0; bx < g.bx[k]; ++bx) {
+			const int mx = bx / g.H[k], h = bx % g.H[k], my = by / g.V[k], v = by % g.V[k];
+			const size_t blk = (size_t)(my * g.m_x + mx) * g.B + g.comp_first[k] + v * g.H[k] + h;
+			const int32_t *src = in + ((size_t)by * g.bx[k] + bx) * 64;
+			for (int z = 0; z < 64; ++z) {
+				const int32_t c = src[jh_zigzag[z]];
+				fits = fits && c >= -32768 && c <= 32767;
+				fc[blk * 64 + z] = (int16_t)c;
+			}
+		}
+	}
+	return fits;
+}
+
+static int geom_from_desc(const jpeg_hip_frame_desc *fd, JhGeom *g)
+{
+	memset(g, 0, sizeof *g);
+	if (!fd || fd->Nf < 1 || fd->Nf > JH_MAX_COMP || fd->X <= 0 || fd->Y <= 0 || fd->X > 65535 || fd->Y > 65535) {
+		return RET_FAILURE_FILE_UNSUPPORTED;
+	}
+	g->P = fd->P; g->X = fd->X; g->Y = fd->Y; g->Nf = fd->Nf; g->ncomp = fd->Nf;
+	for (int k = 0; k < fd->Nf; ++k) {
+		if (fd->Tq[k] < 0 || fd->Tq[k] > 3 || fd->H[k] < 1 || fd->H[k] > 4 || fd->V[k] < 1 || fd->V[k] > 4) {
+			return RET_FAILURE_FILE_UNSUPPORTED;
+		}
+		g->id[k] = k + 1;
+		g->H[k] = fd->H[k];
+		g->V[k] = fd->V[k];
+		g->Tq[k] = fd->Tq[k];
+		g->scan_order[k] = k;
+	}
+	return RET_SUCCESS;
+}
+
+static void spec_from_htable(const jpeg_hip_htable *t, JhHuffSpec *s)
+{
+	memcpy(s->L, t->L, 16);
+	memcpy(s->V, t->V, 256);
+}
+
+extern "C" int jpeg_hip_read_scan(int device, const jpeg_hip_frame_desc *frame, const jpeg_hip_scan_desc *scan,
+                                  const jpeg_hip_htable dc[4], const jpeg_hip_htable ac[4],
+                                  const uint8_t *ecs, size_t n, int32_t *const coef[JPEG_HIP_MAX_COMP], size_t *consumed)
+{
+	int err = require_device(device);
+	if (err) {
+		return err;
+	}
+	if (!frame || !scan || !dc || !ac || !ecs || !coef) {
+		return RET_FAILURE_LOGIC_ERROR;
+	}
+	JhHeader h;
+	memset(&h, 0, sizeof h);
+	err = geom_from_desc(frame, &h.g);
+	if (err) {
+		return err;
+	}
+	if (scan->Ns < 1 || scan->Ns > frame->Nf) {
+		return RET_FAILURE_FILE_UNSUPPORTED;
+	}
+	ScanDesc sd;
+	memset(&sd, 0, sizeof sd);
+	unsigned seen = 0;
+	for (int j = 0; j < JH_MAX_COMP; ++j) {
+		sd.cs[j] = -1;
+	}
+	for (int j = 0; j < scan->Ns; ++j) {
+		const int k = scan->Cs[j];
+		if (k < 0 || k >= frame->Nf || (seen & (1u << k)) || scan->Td[j] < 0 || scan->Td[j] > 3 ||
+		    scan->Ta[j] < 0 || scan->Ta[j] > 3) {
+			return RET_FAILURE_FILE_UNSUPPORTED;
+		}
+		seen |= 1u << k;
+		sd.cs[j] = k;
+		sd.Td[k] = h.g.Td[k] = scan->Td[j];
+		sd.Ta[k] = h.g.Ta[k] = scan->Ta[j];
+	}
+	sd.ncs = scan->Ns;
+	if (scan->Ns == frame->Nf) {
+		sd.comp = -1;                                      // every component: the MCU follows the scan header's order
+		for (int j = 0; j < scan->Ns; ++j) {
+			h.g.scan_order[j] = scan->Cs[j];
+		}
+	} else {
+		sd.comp = scan->Ns == 1 ? scan->Cs[0] : -2;
+	}
+	for (int th = 0; th < 4; ++th) {
+		spec_from_htable(&dc[th], &sd.ht[0][th]);
+		spec_from_htable(&ac[th], &sd.ht[1][th]);
+	}
+	sd.ecs_begin = 0;
+	sd.ecs_end = n;
+	sd.Ri = scan->restart_interval > 0 ? scan->restart_interval : 0;
+	h.g.Ri = sd.Ri;
+	h.Ns = scan->Ns;
+	for (int t = 0; t < 4; ++t) {
+		for (int i = 0; i < 64; ++i) {
+			h.Q[t][i] = 1;                                 // not used: the run stops at the coefficients
+		}
+	}
+
+	jpeg_hip_decoder *dec = nullptr;
+	err = jpeg_hip_decoder_create(&dec, device);
+	if (err) {
+		return err;
+	}
+	dec->coefs_only = true;
+	const uint8_t *bufs[1] = {ecs};
+	const size_t lens[1] = {n};
+	err = decoder_prepare(dec, 1, bufs, lens, [&](int, JhHeader *ho, std::vector<ScanDesc> *sc) {
+		*ho = h;
+		sc->assign(1, sd);
+		return RET_SUCCESS;
+	});
+	int status = RET_SUCCESS;
+	if (!err) {
+		dec->last_out = nullptr;
+		dec->last_stride = 0;
+		dec->last_stream = nullptr;
+		dec->timer.reset();
+		err = decoder_launch(dec, nullptr);
+		dec->ran = err == RET_SUCCESS;
+	}
+	if (!err) {
+		jpeg_hip_decoder_sync(dec, &status);
+		if (consumed) {
+			*consumed = dec->ecs_len[0];
+		}
+		// read_ecs() fails with what read_marker() returns at the end of the data; the blocks decoded until
+		// then are in the buffers all the same
+		for (int j = 0; j < scan->Ns && !err; ++j) {
+			if (coef[scan->Cs[j]]) {
+				err = jpeg_hip_decoder_get_coefficients(dec, 0, scan->Cs[j], coef[scan->Cs[j]]);
+			}
+		}
+	}
+	jpeg_hip_decoder_destroy(dec);
+	return err ? err : status;
+}
+
+extern "C" int jpeg_hip_decode_pixels(int device, const jpeg_hip_frame_desc *frame, const uint16_t Q[4][64],
+                                      const int32_t *const coef[JPEG_HIP_MAX_COMP], void *samples)
+{
+	int err = require_device(device);
+	if (err) {
+		return err;
+	}
+	if (!frame || !Q || !coef || !samples) {
+		return RET_FAILURE_LOGIC_ERROR;
+	}
+	JhGeom g;
+	err = geom_from_desc(frame, &g);
+	if (!err) {
+		err = jh_finish_geometry(&g);
+	}
+	if (err) {
+		return err;
+	}
+	const size_t ncoef = (size_t)g.nblk * 64;
+	std::vector<int16_t> fc(ncoef, 0);
+	for (int k = 0; k < g.ncomp; ++k) {
+		if (!coef[k]) {
+			return RET_FAILURE_LOGIC_ERROR;
+		}
+		if (!reference_layout_to_coefs(g, k, coef[k], fc.data())) {
+			return RET_FAILURE_FILE_UNSUPPORTED;           // beyond 16 bits: no baseline stream holds such a coefficient
+		}
+	}
+	JhQuant q;
+	for (int t = 0; t < 4; ++t) {
+		for (int z = 0; z < 64; ++z) {
+			q.q[t][z] = Q[t][jh_zigzag[z]];
+		}
+	}
+	const size_t body = (size_t)g.X * g.Y * g.out_comps * g.sample_bytes;
+	int16_t *d_coefs = nullptr;
+	JhQuant *d_quant = nullptr;
+	void *d_out = nullptr;
+	hipError_t e = hipMalloc((void **)&d_coefs, ncoef * sizeof(int16_t));
+	e = e == hipSuccess ? hipMalloc((void **)&d_quant, sizeof q) : e;
+	e = e == hipSuccess ? hipMalloc(&d_out, body) : e;
+	e = e == hipSuccess ? hipMemcpy(d_coefs, fc.data(), ncoef * sizeof(int16_t), hipMemcpyHostToDevice) : e;
+	e = e == hipSuccess ? hipMemcpy(d_quant, &q, sizeof q, hipMemcpyHostToDevice) : e;
+	int r = RET_SUCCESS;
+	if (e != hipSuccess) {
+		r = RET_FAILURE_MEMORY_ALLOCATION;
+	} else if (jh_launch_decode_pixels(g, 1, d_coefs, d_quant, d_out, body, nullptr)) {
+		r = RET_FAILURE_LOGIC_ERROR;
+	} else if (hipMemcpy(samples, d_out, body, hipMemcpyDeviceToHost) != hipSuccess) {
+		r = RET_FAILURE_LOGIC_ERROR;
+	}
+	hipFree(d_coefs);
+	hipFree(d_quant);
+	hipFree(d_out);
+	return r;
+}
+
+// frames the reference encoder sets up (encoder.c:109-146), and its parameters
+static int encoder_frame_params(const jpeg_hip_frame_desc *fd, jpeg_hip_params *prm)
+{
+	if (!fd || (fd->Nf != 1 && fd->Nf != 3)) {
+		return RET_FAILURE_FILE_UNSUPPORTED;
+	}
+	memset(prm, 0, sizeof *prm);
+	prm->H = prm->V = 1;
+	prm->q = 75;
+	if (fd->Nf == 3) {
+		if (fd->H[1] != 1 || fd->V[1] != 1 || fd->H[2] != 1 || fd->V[2] != 1 || fd->H[0] < 1 || fd->H[0] > 2 ||
+		    fd->V[0] < 1 || fd->V[0] > 2 || fd->Tq[0] != 0 || fd->Tq[1] != 1 || fd->Tq[2] != 1) {
+			return RET_FAILURE_FILE_UNSUPPORTED;
+		}
+		prm->H = (uint8_t)fd->H[0];
+		prm->V = (uint8_t)fd->V[0];
+	} else if (fd->Tq[0] != 0) {
+		return RET_FAILURE_FILE_UNSUPPORTED;
+	}
+	return RET_SUCCESS;
+}
+
+extern "C" int jpeg_hip_encode_pixels(int device, const jpeg_hip_frame_desc *frame, const uint16_t Q[4][64],
+                                      const void *samples, int32_t *const coef[JPEG_HIP_MAX_COMP])
+{
+	int err = require_device(device);
+	if (err) {
+		return err;
+	}
+	if (!frame || !Q || !samples || !coef) {
+		return RET_FAILURE_LOGIC_ERROR;
+	}
+	jpeg_hip_params prm;
+	err = encoder_frame_params(frame, &prm);
+	if (err) {
+		return err;
+	}
+	for (int t = 0; t < (frame->Nf > 1 ? 2 : 1); ++t) {
+		for (int i = 0; i < 64; ++i) {
+			if (Q[t][i] == 0) {
+				return RET_FAILURE_FILE_UNSUPPORTED;       // quantize_block() would divide by zero
+			}
+		}
+	}
+	jpeg_hip_encoder *enc = nullptr;
+	err = jpeg_hip_encoder_create(&enc, device);
+	if (err) {
+		return err;
+	}
+	err = encoder_configure(enc, 1, frame->X, frame->Y, frame->Nf, frame->P, &prm, Q, nullptr);
+	void *d_in = nullptr;
+	if (!err) {
+		const JhGeom &g = enc->g;
+		const size_t body = (size_t)g.X * g.Y * g.Nf * g.sample_bytes;
+		if (hipMalloc(&d_in, body) != hipSuccess || hipMemcpy(d_in, samples, body, hipMemcpyHostToDevice) != hipSuccess) {
+			err = RET_FAILURE_MEMORY_ALLOCATION;
+		} else if (jh_launch_encode_pixels(g, 1, d_in, body, enc->d_quant, enc->d_coefs, nullptr) ||
+		           hipStreamSynchronize(nullptr) != hipSuccess) {
+			err = RET_FAILURE_LOGIC_ERROR;
+		}
+		enc->ran = !err;
+		for (int k = 0; k < g.ncomp && !err; ++k) {
+			if (coef[k]) {
+				err = jpeg_hip_encoder_get_coefficients(enc, 0, k, coef[k]);
+			}
+		}
+	}
+	hipFree(d_in);
+	jpeg_hip_encoder_destroy(enc);
+	return err;
+}
+
+extern "C" int jpeg_hip_write_scan(int device, const jpeg_hip_frame_desc *frame, const jpeg_hip_scan_desc *scan,
+                                   jpeg_hip_htable dc[4], jpeg_hip_htable ac[4], int optimize,
+                                   const int32_t *const coef[JPEG_HIP_MAX_COMP], uint8_t *out, size_t cap, size_t *n)
+{
+	int err = require_device(device);
+	if (err) {
+		return err;
+	}
+	if (!frame || !scan || !dc || !ac || !coef || !n || (!out && cap)) {
+		return RET_FAILURE_LOGIC_ERROR;
+	}
+	*n = 0;
+	jpeg_hip_params prm;
+	err = encoder_frame_params(frame, &prm);
+	if (err) {
+		return err;
+	}
+	// the reference encoder's one scan: all components in frame order, tables 0 / 1 / 1 (encoder.c:139-141, 329-346)
+	if (scan->Ns != frame->Nf || scan->restart_interval < 0 || scan->restart_interval > 65535) {
+		return RET_FAILURE_FILE_UNSUPPORTED;
+	}
+	for (int j = 0; j < scan->Ns; ++j) {
+		const int want = j == 0 ? 0 : 1;
+		if (scan->Cs[j] != j || scan->Td[j] != want || scan->Ta[j] != want || !coef[j]) {
+			return RET_FAILURE_FILE_UNSUPPORTED;
+		}
+	}
+	prm.optimize = optimize != 0;
+	prm.restart_interval = scan->restart_interval;
+	JhHuffSpec ht[2][4];
+	for (int th = 0; th < 4; ++th) {
+		const int src = frame->Nf > 1 ? (th & 1) : 0;      // one component: table 0 only
+		spec_from_htable(&dc[src], &ht[0][th]);
+		spec_from_htable(&ac[src], &ht[1][th]);
+	}
+	uint16_t Q[4][64];
+	for (int t = 0; t < 4; ++t) {
+		for (int i = 0; i < 64; ++i) {
+			Q[t][i] = 1;                                   // the headers built on the side are not used
+		}
+	}
+	jpeg_hip_encoder *enc = nullptr;
+	err = jpeg_hip_encoder_create(&enc, device);
+	if (err) {
+		return err;
+	}
+	err = encoder_configure(enc, 1, frame->X, frame->Y, frame->Nf, frame->P, &prm, Q, optimize ? nullptr : ht);
+	if (!err) {
+		const JhGeom &g = enc->g;
+		const JhEncodeWork &w = enc->work;
+		const size_t ncoef = (size_t)g.nblk * 64;
+		std::vector<int16_t> fc(ncoef, 0);
+		bool fits = true;
+		for (int k = 0; k < g.ncomp; ++k) {
+			fits = reference_layout_to_coefs(g, k, coef[k], fc.data()) && fits;
+		}
+		if (!fits) {
+			err = JPEG_HIP_ERR_NO_CODE;                    // category 16 and up: no table has a code (coeffs.c:56-74)
+		} else if (hipMemcpy(enc->d_coefs, fc.data(), ncoef * sizeof(int16_t), hipMemcpyHostToDevice) != hipSuccess ||
+		           hipMemsetAsync(enc->d_state, 0, sizeof(JhEncState), nullptr) != hipSuccess) {
+			err = RET_FAILURE_LOGIC_ERROR;
+		} else if ((optimize && (jh_launch_enc_histogram(w, g, nullptr, nullptr) || jh_launch_enc_adapt(w, g, nullptr, nullptr))) ||
+		           jh_launch_enc_entropy(w, g, nullptr, nullptr)) {
+			err = RET_FAILURE_LOGIC_ERROR;
+		}
+	}
+	if (!err) {
+		enc->last_stream = nullptr;
+		enc->ran = true;
+		int status = RET_SUCCESS;
+		size_t total = 0;
+		jpeg_hip_encoder_sync(enc, &status, &total);
+		err = status;
+		if (!err) {
+			const size_t ecs = enc->state[0].ecs_bytes;
+			*n = ecs;
+			if (ecs > cap) {
+				err = RET_FAILURE_OVERFLOW_ERROR;
+			} else if (hipMemcpy(out, enc->d_out + enc->hdr_len[0], ecs, hipMemcpyDeviceToHost) != hipSuccess) {
+				err = RET_FAILURE_LOGIC_ERROR;
+			}
+		}
+		if (!err && optimize) {
+			// the tables the device derived (k_enc_adapt), for the caller's DHT segments
+			JhDevSpec specs[4];
+			if (hipMemcpy(specs, enc->d_specs, sizeof specs, hipMemcpyDeviceToHost) != hipSuccess) {
+				err = RET_FAILURE_LOGIC_ERROR;
+			} else {
+				for (int th = 0; th < (frame->Nf > 1 ? 2 : 1); ++th) {
+					memcpy(dc[th].L, specs[0 * 2 + th].L, 16);
+					memcpy(dc[th].V, specs[0 * 2 + th].V, 256);
+					memcpy(ac[th].L, specs[1 * 2 + th].L, 16);
+					memcpy(ac[th].V, specs[1 * 2 + th].V, 256);
+				}
+			}
+		}
+	}
+	jpeg_hip_encoder_destroy(enc);
+	return err;
+}
+
 
 static int slurp(FILE *f, std::vector<uint8_t> *out)
 {

@@ -263,7 +263,6 @@ __global__ __launch_bounds__(256) void k_huff_chains(const HuffArgs a)
 	__shared__ uint16_t alive[2][256];
 	__shared__ int nalive[2];
 	__shared__ PathLds P;
-	__shared__ Agg total;
 
 	const JhDecodeWork &w = a.w;
 	const int f = blockIdx.y;

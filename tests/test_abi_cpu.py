@@ -31,7 +31,8 @@ def test_header_symbols_are_exported(built_lib):
 def test_every_entry_point_cites_the_reference(built_lib):
     hdr = open(os.path.join(ROOT, "include", "jpeg_amd.h")).read()
     for ref in ("decoder.c:364", "decoder.c:456", "encoder.c:176", "encoder.c:525", "decoder.c:661",
-                "decoder.c:687", "encoder.c:647", "common.h:15-31"):
+                "decoder.c:687", "encoder.c:647", "common.h:15-31", "decoder.c:364-388", "decoder.c:456-470",
+                "encoder.c:176-193", "encoder.c:525-587"):
         assert ref in hdr
 
 
@@ -39,6 +40,10 @@ def test_struct_layouts_match_header(built_lib):
     # jpeg_hip_frame_info: 4 + 6*4 + 6 + 2*4 + 4 ints
     assert C.sizeof(built_lib.FrameInfo) == 4 * (4 + 24 + 6 + 8 + 4)
     assert C.sizeof(built_lib.Params) == 16
+    # stage level: jpeg_hip_frame_desc 4 + 3*4 ints, jpeg_hip_htable 16 + 256 bytes, jpeg_hip_scan_desc 1 + 3*4 + 1 ints
+    assert C.sizeof(built_lib.FrameDesc) == 4 * 16
+    assert C.sizeof(built_lib.HTable) == 272
+    assert C.sizeof(built_lib.ScanDesc) == 4 * 14
 
 
 def test_fails_loudly_without_gpu(built_lib):
@@ -51,5 +56,14 @@ def test_fails_loudly_without_gpu(built_lib):
     assert L.jpeg_hip_encoder_create(C.byref(h), 0) == built_lib.RET_FAILURE_LOGIC_ERROR
     with pytest.raises(built_lib.JpegError):
         built_lib.Decoder()
+    # the stage level entry points refuse as well
+    import numpy as np
+    fd = built_lib.frame_desc(16, 16, 8, [1], [1], [0])
+    sd = built_lib.scan_desc([0], [0], [0])
+    tabs = built_lib.htables([None] * 4)
+    assert built_lib.read_scan(fd, sd, tabs, tabs, b"\x00\xff\xd9")[0] == built_lib.RET_FAILURE_LOGIC_ERROR
+    assert built_lib.decode_pixels(fd, np.ones((4, 64), np.uint16), [np.zeros((4, 64), np.int32)])[0] == built_lib.RET_FAILURE_LOGIC_ERROR
+    assert built_lib.encode_pixels(fd, np.ones((4, 64), np.uint16), np.zeros((16, 16), np.uint8))[0] == built_lib.RET_FAILURE_LOGIC_ERROR
+    assert built_lib.write_scan(fd, sd, tabs, tabs, 1, [np.zeros((4, 64), np.int32)])[0] == built_lib.RET_FAILURE_LOGIC_ERROR
     # the drop-in entry points refuse too (no silent CPU path)
     assert L.jpeg_hip_process_jpeg_file(b"/nonexistent.jpg", None) == 0x1002  # RET_FAILURE_FILE_OPEN first

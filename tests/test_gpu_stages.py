@@ -1,0 +1,198 @@
+"""Stage-level entry points (include/jpeg_amd.h: jpeg_hip_read_scan, jpeg_hip_decode_pixels,
+jpeg_hip_encode_pixels, jpeg_hip_write_scan) against the oracle, through the C-ABI.
+
+These are the four hot loops as a maintainer would call them from inside the reference's own
+parse_format() / produce_codestream(): read_ecs (decoder.c:364-388), epilogue
+(decoder.c:456-470), prologue (encoder.c:176-193), write_ecs_dry + write_ecs (encoder.c:525-587).  The
+marker walk below plays the part of parse_format(); every stage result is compared bit for bit with what the
+oracle holds at the same stage boundary."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from jpeg_amd.synth import synth_image
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from jpeg_amd import binding
+    assert binding.lib().jpeg_hip_device_count() > 0, "no HIP device: the product path has no CPU fallback"
+    return binding
+
+
+def walk_scans(jpg):
+    """A minimal parse_format(): -> list of (component ids, Td, Ta, ecs offset, offset of the ending marker)."""
+    pos, scans = 2, []
+    while pos + 4 <= len(jpg):
+        assert jpg[pos] == 0xFF
+        m = jpg[pos + 1]
+        if m == 0xD9:
+            break
+        n = (jpg[pos + 2] << 8) | jpg[pos + 3]
+        if m == 0xDA:
+            ns = jpg[pos + 4]
+            ids = [jpg[pos + 5 + 2 * j] for j in range(ns)]
+            tt = [jpg[pos + 6 + 2 * j] for j in range(ns)]
+            begin = pos + 2 + n
+            end = begin
+            while not (jpg[end] == 0xFF and jpg[end + 1] != 0 and not 0xD0 <= jpg[end + 1] <= 0xD7):
+                end += 1
+            scans.append((ids, [t >> 4 for t in tt], [t & 15 for t in tt], begin, end))
+            pos = end
+        else:
+            pos += 2 + n
+    return scans
+
+
+def descs(hip, info, ids=None, Td=None, Ta=None, ri=0):
+    fd = hip.frame_desc(info.X, info.Y, info.P, [c["H"] for c in info.comps], [c["V"] for c in info.comps],
+                        [c["Tq"] for c in info.comps])
+    if ids is None:
+        return fd
+    index = {c["id"]: k for k, c in enumerate(info.comps)}
+    return fd, hip.scan_desc([index[i] for i in ids], Td, Ta, ri)
+
+
+def tables(hip, info):
+    return (hip.htables([info.htables[(0, th)] for th in range(4)]),
+            hip.htables([info.htables[(1, th)] for th in range(4)]))
+
+
+CASES = [
+    # X, Y, Nf, P, H, V, q, optimize, restart interval
+    (200, 136, 3, 8, 2, 2, 85, 1, 0),
+    (333, 211, 3, 8, 2, 1, 70, 0, 7),
+    (160, 120, 3, 8, 1, 1, 92, 1, 20),
+    (257, 129, 1, 8, 1, 1, 80, 0, 0),
+    (192, 160, 1, 12, 1, 1, 60, 1, 0),
+    (1280, 720, 3, 8, 2, 2, 90, 1, 0),            # several workgroups per kernel
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_every_stage_matches_the_oracle(hip, oracle, case):
+    X, Y, Nf, P, H, V, q, opt, ri = case
+    img = synth_image(X, Y, Nf, P, seed=31, range_safe=P > 8)
+    err, jpg, einfo = oracle.encode(img, P=P, H=H, V=V, q=q, optimize=opt, restart_interval=ri)
+    assert err == 0
+    err, opx, dinfo = oracle.decode(jpg)
+    assert err == 0
+    (ids, Td, Ta, begin, end), = walk_scans(jpg)
+    fd, sd = descs(hip, dinfo, ids, Td, Ta, ri)
+    dc, ac = tables(hip, dinfo)
+
+    # prologue: samples -> quantised coefficients
+    err, coefs = hip.encode_pixels(fd, einfo.qtables, img)
+    assert err == 0
+    for k, c in enumerate(einfo.comps):
+        assert np.array_equal(coefs[k], c["coef"]), "encode_pixels, component %d" % k
+
+    # write_ecs[_dry]: coefficients -> entropy-coded bytes (and the adapted tables)
+    wdc, wac = (hip.htables([None] * 4), hip.htables([None] * 4)) if opt else tables(hip, einfo)
+    err, ecs = hip.write_scan(fd, sd, wdc, wac, opt, coefs)
+    assert err == 0
+    assert ecs == jpg[begin:end]
+    if opt:
+        for th in range(2 if Nf > 1 else 1):
+            for tc, got in ((0, wdc), (1, wac)):
+                Lw, Vw = einfo.htables[(tc, th)]
+                nsym = int(np.sum(Lw))
+                assert list(got[th].L) == list(Lw) and list(got[th].V)[:nsym] == list(Vw[:nsym])
+
+    # read_ecs: entropy-coded bytes -> coefficients
+    err, got, used = hip.read_scan(fd, sd, dc, ac, jpg[begin:])
+    assert err == 0 and used == end - begin
+    for k, c in enumerate(dinfo.comps):
+        assert np.array_equal(got[k], c["coef"]), "read_scan, component %d" % k
+
+    # epilogue: coefficients -> samples
+    err, px = hip.decode_pixels(fd, dinfo.qtables, [got[k] for k in range(Nf)])
+    assert err == 0
+    assert np.array_equal(px, opx)
+
+
+@pytest.mark.parametrize("split", [0, 1, 2])
+def test_read_scan_on_frames_coded_in_several_scans(hip, oracle, split):
+    """The call the reference makes once per SOS marker (decoder.c:593-601): each scan fills the buffers of
+    its own components; together they are the frame the oracle decodes."""
+    img = synth_image(264, 200, 3, 8, seed=32)
+    for (H, V, ri) in [(2, 2, 0), (2, 1, 6), (1, 1, 9)]:
+        err, jpg = oracle.encode_scans(img, P=8, H=H, V=V, q=85, optimize=1, restart_interval=ri, split=split)
+        assert err == 0
+        err, opx, info = oracle.decode(jpg)
+        assert err == 0
+        dc, ac = tables(hip, info)
+        merged = {}
+        for ids, Td, Ta, begin, end in walk_scans(jpg):
+            fd, sd = descs(hip, info, ids, Td, Ta, ri)
+            err, got, used = hip.read_scan(fd, sd, dc, ac, jpg[begin:])
+            assert err == 0 and used == end - begin
+            assert sorted(got) == sorted(sd.Cs[j] for j in range(sd.Ns))
+            merged.update(got)
+        for k, c in enumerate(info.comps):
+            assert np.array_equal(merged[k], c["coef"])
+        err, px = hip.decode_pixels(fd, info.qtables, [merged[k] for k in range(3)])
+        assert err == 0 and np.array_equal(px, opx)
+
+
+def test_decode_pixels_on_external_frames(hip, oracle):
+    """epilogue() on frames of other encoders: four components (YCCK -> RGB, frame.c:196-217), 4:2:0 with
+    libjpeg's tables, gray."""
+    with open(os.path.join(HERE, "golden", "manifest.json")) as f:
+        man = json.load(f)["decode"]
+    for name in ("d_pil_cmyk", "d_pil_420_rst_2mcu", "d_pil_gray", "d_pil_444_rst_row"):
+        if name not in man:
+            pytest.skip("fixture %s absent" % name)
+        with open(os.path.join(HERE, "golden", man[name]["jpg_file"]), "rb") as f:
+            jpg = f.read()
+        err, opx, info = oracle.decode(jpg)
+        assert err == 0
+        fd = descs(hip, info)
+        err, px = hip.decode_pixels(fd, info.qtables, [c["coef"] for c in info.comps])
+        assert err == 0
+        assert np.array_equal(px, opx), name
+
+
+def test_stage_error_behaviour(hip, oracle):
+    img = synth_image(96, 64, 3, 8, seed=33)
+    err, jpg, einfo = oracle.encode(img, P=8, H=2, V=2, q=80, optimize=0)
+    assert err == 0
+    (ids, Td, Ta, begin, end), = walk_scans(jpg)
+    fd, sd = descs(hip, einfo, ids, Td, Ta)
+    dc, ac = tables(hip, einfo)
+    coefs = [c["coef"] for c in einfo.comps]
+    # data that ends without a marker: read_marker() meets the end of the file (io.c:197)
+    err, got, used = hip.read_scan(fd, sd, dc, ac, jpg[begin:end])
+    assert err == hip.RET_FAILURE_FILE_IO
+    # ... but whatever was complete is in the buffers, as after a failed read_ecs()
+    assert np.array_equal(got[1], coefs[1])
+    # output buffer too small: the length needed comes back
+    import ctypes as C
+    n = C.c_size_t(0)
+    small = np.zeros(16, np.uint8)
+    ptrs = (C.c_void_p * 4)(*[c.ctypes.data for c in coefs], None)
+    err = hip.lib().jpeg_hip_write_scan(0, C.byref(fd), C.byref(sd), dc, ac, 0, ptrs, small.ctypes.data, 16, C.byref(n))
+    assert err == hip.RET_FAILURE_OVERFLOW_ERROR and n.value == end - begin
+    # a coefficient the default tables have no code for (value_to_vlc() == -1, huffman.c:252)
+    bad = [c.copy() for c in coefs]
+    bad[0][5, 9] = 3000
+    assert hip.write_scan(fd, sd, dc, ac, 0, bad)[0] == hip.JPEG_HIP_ERR_NO_CODE
+    # |DC difference| > 2047: assert in the reference (encoder.c:447)
+    bad = [c.copy() for c in coefs]
+    bad[2][3, 0] = 2500
+    assert hip.write_scan(fd, sd, dc, ac, 1, bad)[0] == hip.JPEG_HIP_ERR_DC_RANGE
+    # frames the reference encoder never sets up
+    odd = hip.frame_desc(96, 64, 8, [2, 2, 1], [1, 1, 1], [0, 1, 1])
+    assert hip.encode_pixels(odd, einfo.qtables, img)[0] == hip.RET_FAILURE_FILE_UNSUPPORTED
+    zero = einfo.qtables.copy()
+    zero[1, 7] = 0
+    assert hip.encode_pixels(fd, zero, img)[0] == hip.RET_FAILURE_FILE_UNSUPPORTED
+    # a scan that names a component twice
+    twice = hip.scan_desc([0, 0], [0, 0], [0, 0])
+    assert hip.read_scan(fd, twice, dc, ac, jpg[begin:])[0] == hip.RET_FAILURE_FILE_UNSUPPORTED
