@@ -194,6 +194,7 @@ struct jpeg_hip_decoder {
 	std::vector<DecPass> pass;
 	std::vector<int> parse_err;
 	std::vector<size_t> ecs_len;
+	std::vector<size_t> file_off, file_len;   // the frames inside h_stage (valid until the next prepare)
 	// device
 	uint8_t *d_raw = nullptr;
 	uint8_t *h_stage = nullptr;       // pinned staging for the codestreams, kept between prepare() calls
@@ -391,7 +392,9 @@ static int decoder_prepare(jpeg_hip_decoder *dec, int nframes, const uint8_t *co
 	std::vector<JhHeader> hdr(nframes);
 	std::vector<std::vector<ScanDesc>> scans(nframes);
 	std::vector<JhQuant> quant(nframes);
-	std::vector<size_t> file_off(nframes);
+	std::vector<size_t> &file_off = dec->file_off;
+	file_off.assign(nframes, 0);
+	dec->file_len.assign(jpg_len, jpg_len + nframes);
 	std::vector<ScanDesc> pass_comp;                       // the batch's scan structure (from the first good frame)
 	bool have_geom = false;
 	size_t raw_off = 0;
@@ -820,7 +823,26 @@ extern "C" int jpeg_hip_decoder_sync(jpeg_hip_decoder *dec, int *frame_status)
 			} else if (ds.term_pos + 1 >= fr.raw_end) {
 				st = RET_FAILURE_FILE_IO;            // no EOI (or a lone FF as the last byte): read_marker() hits end of file (io.c:197)
 			} else if (pi + 1 == dec->pass.size() && dec->pass[pi].comp == -1 && ds.term_marker != 0xd9 && !dec->coefs_only) {
-				st = RET_FAILURE_FILE_UNSUPPORTED;   // a scan of all components followed by more than EOI: not on the GPU path
+				// A scan of all components that ends on something else than EOI.  parse_format() goes on from
+				// that marker (decoder.c:487-657): TEM, APPn, COM, DAC and table segments pass, whatever
+				// lies between markers is skipped (io.c:196-210), EOI ends the image with what was decoded.
+				// The same walk here, on the host copy of the file.  More entropy-coded data behind it (RSTn
+				// after a stray marker, another SOS) is not on the GPU path, and new quantisation tables would
+				// change the image already made.
+				st = RET_FAILURE_FILE_UNSUPPORTED;
+				JhHeader h0, h1;
+				const uint8_t *file = dec->h_stage + dec->file_off[f];
+				const size_t len = dec->file_len[f];
+				bool eoi = false;
+				if (dec->h_stage && jh_parse_headers(file, len, &h0, dec->tolerant) == RET_SUCCESS) {
+					h1 = h0;
+					const int e = jh_parse_next_scan(file, len, ds.term_pos - dec->file_off[f], &h1, &eoi);
+					if (e == RET_SUCCESS && eoi && memcmp(h0.Q, h1.Q, sizeof h0.Q) == 0) {
+						st = RET_SUCCESS;
+					} else if (e == RET_FAILURE_FILE_IO) {
+						st = e;                          // no EOI behind it: read_marker() meets the end of the file
+					}
+				}
 			}
 		}
 		if (frame_status) {

@@ -245,6 +245,37 @@ def test_garbage_in_the_entropy_coded_data(hip, oracle):
         assert np.array_equal(outs[0][:rows], opx[:rows])
 
 
+def test_stray_markers_inside_the_entropy_coded_data(hip, oracle):
+    """A marker other than RSTn ends read_ecs() (io.c:257-268); parse_format() then goes on from it
+    (decoder.c:487-657): TEM and segments with a length pass, the bytes up to the next marker are skipped
+    (io.c:196-210), EOI ends the image with what was decoded.  Same status here, same samples for every MCU
+    row in front of the marker, mid grey behind it."""
+    img = synth_image(320, 240, 3, 8, seed=8)
+    _, jpg, _ = oracle.encode(img, P=8, H=2, V=2, q=85, optimize=1)
+    sos = jpg.index(b"\xff\xda")
+    start = sos + 2 + ((jpg[sos + 2] << 8) | jpg[sos + 3])
+    mid = start + (len(jpg) - start) // 2
+    for stray in (b"\xff\x01", b"\xff\xfe\x00\x04ab", b"\xff\xe1\x00\x02"):
+        bad = jpg[:mid] + stray + jpg[mid:]
+        err, opx, oinfo = oracle.decode(bad)
+        outs, st = hip.decode([bad])
+        assert err == 0 and st == [0], stray
+        rows = (oinfo.mblocks // oinfo.m_x) * 16
+        assert rows > 0
+        assert np.array_equal(outs[0][:rows], opx[:rows])
+        assert np.array_equal(outs[0][rows + 16:], opx[rows + 16:])
+    # new quantisation tables behind the scan would change the image (the reference dequantises at EOI,
+    # decoder.c:456-470), markers the reference does not know end in its "unhandled marker": both refused
+    dqt = jpg[jpg.index(b"\xff\xdb"):][:69]
+    changed = dqt[:5] + bytes([dqt[5] ^ 3]) + dqt[6:]
+    assert hip.decode([jpg[:mid] + changed + jpg[mid:]])[1] == [0x1001]
+    bad = jpg[:mid] + b"\xff\xe9\x00\x02" + jpg[mid:]            # APP9
+    assert hip.decode([bad])[1] == [0x1001] and oracle.decode(bad)[0] == 0x1001
+    # nothing but data behind the stray marker: read_marker() meets the end of the file
+    bad = jpg[:mid] + b"\xff\x01" + jpg[mid:-2]
+    assert hip.decode([bad])[1] == [0x1000] and oracle.decode(bad)[0] == 0x1000
+
+
 def _cut_intervals(jpg, which, keep=0.55):
     """Drop the tail of the restart intervals listed in `which` (their data then ends inside an MCU)."""
     sos = jpg.index(b"\xff\xda")

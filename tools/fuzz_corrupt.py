@@ -25,7 +25,12 @@ for case in range(N):
     X, Y = rnd.randint(16, 700), rnd.randint(16, 500)
     ri = rnd.choice([0, 0, 3, rnd.randint(1, 60)])
     img = synth_image(X, Y, nc, 8, 5000 * seed + case, False)
-    err, jpg, _ = orc.encode(img, P=8, H=H, V=V, q=rnd.randint(30, 97), optimize=rnd.randint(0, 1), restart_interval=ri)
+    if nc == 3 and rnd.randint(0, 3) == 0:
+        # several scans (one per component, or groups): the damage may also hit the headers between them
+        err, jpg = orc.encode_scans(img, P=8, H=H, V=V, q=rnd.randint(30, 97), optimize=rnd.randint(0, 1),
+                                    restart_interval=ri, redefine=rnd.randint(0, 1), split=rnd.randint(0, 2))
+    else:
+        err, jpg, _ = orc.encode(img, P=8, H=H, V=V, q=rnd.randint(30, 97), optimize=rnd.randint(0, 1), restart_interval=ri)
     if err:
         continue
     sos = jpg.index(b"\xff\xda")
