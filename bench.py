@@ -133,8 +133,52 @@ def cpu_baseline(imgs, jpgs, cfg, budget_s=20.0):
     }
 
 
+def cpu_worker(seconds):
+    """One host core of the Motion-JPEG CPU baseline (started by cpu_baseline_mjpeg as a child process; no
+    GPU, no torch): the compiled reference decodes and encodes 1080p 4:2:2 q85 frames until the time is up."""
+    from jpeg_amd import synth
+    from oracle.pyoracle import Reference
+    ref = Reference()
+    X, Y, nc, P, H, V, q, opt, safe, seed = synth.CONFIGS["c5_1080p_422_q85"]
+    imgs = [synth.synth_image(X, Y, nc, P, seed, safe, frame=i) for i in range(2)]
+    jpgs = [ref.encode(im, P=P, H=H, V=V, q=q, optimize=opt)[1] for im in imgs]
+    n = 0
+    t_dec = t_enc = 0.0
+    t_start = time.perf_counter()
+    while time.perf_counter() - t_start < seconds:
+        t0 = time.perf_counter()
+        e = ref.decode(jpgs[n % 2])[0]
+        t1 = time.perf_counter()
+        e2 = ref.encode(imgs[n % 2], P=P, H=H, V=V, q=q, optimize=opt)[0]
+        t2 = time.perf_counter()
+        assert e == 0 and e2 == 0
+        t_dec += t1 - t0
+        t_enc += t2 - t1
+        n += 1
+    print(json.dumps({"frames": n, "t_dec": t_dec, "t_enc": t_enc}))
+
+
+def cpu_baseline_mjpeg(seconds=8.0):
+    """frames are independent, so the CPU side of the Motion-JPEG comparison is N copies of the
+    single-threaded reference on N host cores (N = this box's CPU share, at most 16).  Children of this
+    process, each a plain python without GPU."""
+    import subprocess
+    cores = max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)))
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(seconds)],
+                              stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, cwd=ROOT) for _ in range(cores)]
+    dec = enc = 0.0
+    for p in procs:
+        out, _ = p.communicate(timeout=seconds * 6 + 60)
+        r = json.loads(out.decode().strip().splitlines()[-1])
+        dec += r["frames"] / r["t_dec"]
+        enc += r["frames"] / r["t_enc"]
+    return {"decode_frames_per_s": round(dec, 1), "encode_frames_per_s": round(enc, 1), "cores": cores,
+            "sample": "%d processes x %.0f s of decode + encode of 1080p 4:2:2 q85 frames, compiled reference" % (cores, seconds)}
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--cpu-worker", type=float, default=0.0, help=argparse.SUPPRESS)
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
@@ -148,6 +192,9 @@ def main():
                     help="decode and encode on ONE stream (for rocprofv3 --stats: kernels of the two pipelines then "
                          "do not overlap and their durations are the ones `kernel_ms` reports)")
     args = ap.parse_args()
+    if args.cpu_worker > 0:
+        cpu_worker(args.cpu_worker)
+        return
 
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -267,6 +314,11 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_cpu:
         res["cpu_baseline"] = cpu_baseline(imgs, jpgs, cfg)
+        if not args.no_mjpeg:
+            try:
+                res["cpu_baseline"]["mjpeg_1080p_422_q85"] = cpu_baseline_mjpeg()
+            except Exception as e:                         # the headline line must not depend on this extra
+                res["cpu_baseline"]["mjpeg_1080p_422_q85"] = {"error": repr(e)[:200]}
     if rank == 0:
         print(json.dumps(res))
     if dist is not None:
