@@ -807,8 +807,49 @@ extern "C" int jpeg_hip_decoder_sync(jpeg_hip_decoder *dec, int *frame_status)
 	}
 	HIPCHK(hipSetDevice(dec->device));
 	HIPCHK(hipStreamSynchronize(dec->last_stream));
-	for (DecPass &ps : dec->pass) {
-		HIPCHK(hipMemcpy(ps.state.data(), ps.d_state, dec->nframes * sizeof(JhDecState), hipMemcpyDeviceToHost));
+	for (int attempt = 0;; ++attempt) {
+		for (DecPass &ps : dec->pass) {
+			HIPCHK(hipMemcpy(ps.state.data(), ps.d_state, dec->nframes * sizeof(JhDecState), hipMemcpyDeviceToHost));
+		}
+		// The restart-segment tables are sized from DRI.  The reference never looks at Ri (quirk Q1): the
+		// markers decide, and a file may hold more of them than its header promised (or none was sent).
+		// The device counted them all the same: size the tables from that count and run once more.
+		bool again = false;
+		for (DecPass &ps : dec->pass) {
+			bool grown = false;
+			for (int f = 0; f < dec->nframes; ++f) {
+				if (!dec->parse_err[f] && (ps.state[f].status & JH_ST_SEG_OVERFLOW)) {
+					ps.frames[f].seg_cap = ps.state[f].nseg + 64;
+					grown = true;
+				}
+			}
+			if (!grown) {
+				continue;
+			}
+			again = true;
+			size_t off = 0;
+			for (int f = 0; f < dec->nframes; ++f) {
+				ps.frames[f].seg_off = (uint32_t)off;
+				off += ps.frames[f].seg_cap;
+			}
+			ps.seg_off = off;
+			const size_t seg_entries = off + 4;
+			HIPCHK(dec->grow((void **)&ps.d_seg, seg_entries * 4));
+			HIPCHK(dec->grow((void **)&ps.d_drop, seg_entries * sizeof(unsigned long long)));
+			HIPCHK(hipMemset(ps.d_seg, 0, seg_entries * 4));
+			HIPCHK(hipMemset(ps.d_drop, 0, seg_entries * sizeof(unsigned long long)));
+			HIPCHK(hipMemcpy(ps.d_frames, ps.frames.data(), dec->nframes * sizeof(JhDecFrame), hipMemcpyHostToDevice));
+			ps.work.seg_start = ps.d_seg;
+			ps.work.drop = ps.d_drop;
+		}
+		if (!again || attempt > 0) {
+			break;
+		}
+		const int err = decoder_launch(dec, dec->last_stream);
+		if (err) {
+			return err;
+		}
+		HIPCHK(hipStreamSynchronize(dec->last_stream));
 	}
 	int worst = RET_SUCCESS;
 	for (int f = 0; f < dec->nframes; ++f) {

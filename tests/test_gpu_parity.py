@@ -141,6 +141,37 @@ def test_restart_streams_from_the_oracle_extension(hip, oracle):
         assert np.array_equal(outs[0], oracle.decode(jpg)[1])
 
 
+def test_restart_markers_the_header_does_not_announce(hip, oracle):
+    """The reference never looks at Ri (quirk Q1, decoder.c:622-633): the markers decide.  A stream whose DRI
+    is missing, or promises far fewer markers than come, decodes all the same (the segment tables are sized
+    from DRI first, from the device's own count after that)."""
+    imgs = [synth_image(320, 208, 3, 8, seed=70 + i) for i in range(3)]
+    jpgs = []
+    for im in imgs:
+        err, jpg, _ = oracle.encode(im, P=8, H=2, V=1, q=85, optimize=1, restart_interval=1)
+        assert err == 0
+        jpgs.append(jpg)
+    dri = jpgs[0].index(b"\xff\xdd")
+    no_dri = jpgs[0][:dri] + jpgs[0][dri + 6:]
+    wrong_dri = jpgs[1][:dri + 4] + b"\x7f\xff" + jpgs[1][dri + 6:]
+    for batch in ([no_dri], [wrong_dri], [wrong_dri, jpgs[2][:dri + 4] + b"\x00\x63" + jpgs[2][dri + 6:]]):
+        d = hip.Decoder()
+        d.prepare(batch)
+        out = d.run()
+        assert d.sync() == [0] * len(batch)
+        arrs = d.to_arrays(out)
+        for i, j in enumerate(batch):
+            err, opx, oinfo = oracle.decode(j)
+            assert err == 0
+            _assert_coefs(d.coefficients(i), oinfo)
+            assert np.array_equal(arrs[i], opx)
+        # the same prepared batch once more: the grown tables stay
+        out = d.run()
+        assert d.sync() == [0] * len(batch)
+        assert np.array_equal(d.to_arrays(out)[0], oracle.decode(batch[0])[1])
+        d.close()
+
+
 def test_error_behaviour_matches_reference(hip, oracle):
     img = synth_image(64, 64, 3, 8, seed=3)
     _, jpg, _ = oracle.encode(img, P=8, H=2, V=2, q=80, optimize=1)
