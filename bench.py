@@ -301,7 +301,7 @@ def main():
             enc2.close()
             dec2.close()
             del out2, samples2
-            nb = 16
+            nb = 40                                        # 10 240 frames: the 10 000-frame stream of BASELINE.json
             for _ in range(2):
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
