@@ -76,6 +76,13 @@ typedef struct jpeg_hip_frame_info {
 int jpeg_hip_device_count(void);
 const char *jpeg_hip_version(void);
 
+/* Host only, no GPU needed: the headers of one codestream up to its first SOS, as parse_format() reads them
+ * (decoder.c:472-601: SOI, APPn, DQT, SOF0/SOF1, DHT, DRI, SOS), and the geometry that follows from them
+ * (common.c:156-195).  Returns what the reference returns on the same bytes: RET_FAILURE_FILE_UNSUPPORTED
+ * for progressive / lossless / arithmetic frames and unknown markers, RET_FAILURE_FILE_IO for a file cut
+ * inside the headers.  tolerant: see jpeg_hip_decoder_set_tolerant(). */
+int jpeg_hip_parse_info(const uint8_t *jpg, size_t len, int tolerant, jpeg_hip_frame_info *info);
+
 /* ---- batch decoder ------------------------------------------------------------------------
  * One decoder object owns the device workspace for a batch of frames that share geometry
  * (Motion JPEG: every frame is an independent SOI..EOI codestream, decoder.c:603-612).

@@ -25,7 +25,7 @@ JPEG_HIP_ERR_NO_CODE = -1
 MAX_COMP = 4
 
 EXPORTS = [
-    "jpeg_hip_device_count", "jpeg_hip_version",
+    "jpeg_hip_device_count", "jpeg_hip_version", "jpeg_hip_parse_info",
     "jpeg_hip_decoder_create", "jpeg_hip_decoder_destroy", "jpeg_hip_decoder_prepare",
     "jpeg_hip_decoder_info", "jpeg_hip_decoder_frame_bytes", "jpeg_hip_decoder_run",
     "jpeg_hip_decoder_sync", "jpeg_hip_decoder_get_coefficients", "jpeg_hip_decoder_set_timing",
@@ -100,6 +100,7 @@ def lib():
         L = C.CDLL(LIB_PATH)
         vp, sz, ip = C.c_void_p, C.c_size_t, C.POINTER(C.c_int)
         L.jpeg_hip_version.restype = C.c_char_p
+        L.jpeg_hip_parse_info.argtypes = [C.c_char_p, sz, C.c_int, C.POINTER(FrameInfo)]
         L.jpeg_hip_decoder_create.argtypes = [C.POINTER(vp), C.c_int]
         L.jpeg_hip_decoder_destroy.argtypes = [vp]
         L.jpeg_hip_decoder_destroy.restype = None
@@ -161,6 +162,13 @@ def _timing(fn, handle):
     ms = (C.c_float * 32)()
     n = fn(handle, names, ms, 32)
     return {names[i].decode(): float(ms[i]) for i in range(n)}
+
+
+def parse_info(jpg, tolerant=False):
+    """Headers and geometry of one codestream (host only) -> (RET code, FrameInfo)."""
+    fi = FrameInfo()
+    err = lib().jpeg_hip_parse_info(jpg, len(jpg), int(tolerant), C.byref(fi))
+    return err, fi
 
 
 class Decoder:

@@ -81,6 +81,25 @@ static void fill_info(const JhGeom &g, jpeg_hip_frame_info *o)
 	o->blocks_per_mcu = g.B; o->out_components = g.out_comps; o->sample_bytes = g.sample_bytes;
 }
 
+extern "C" int jpeg_hip_parse_info(const uint8_t *jpg, size_t len, int tolerant, jpeg_hip_frame_info *info)
+{
+	if (!jpg || !info) {
+		return RET_FAILURE_LOGIC_ERROR;
+	}
+	JhHeader h;
+	int err = jh_parse_headers(jpg, len, &h, tolerant != 0);
+	if (!err) {
+		for (int j = 0; j < h.g.ncomp; ++j) {
+			h.g.scan_order[j] = h.Ns == h.g.ncomp ? h.scan_comp[j] : j;   // Ns == 0: no scan before EOI
+		}
+		err = jh_finish_geometry(&h.g);
+	}
+	if (!err) {
+		fill_info(h.g, info);
+	}
+	return err;
+}
+
 // scan-order / zig-zag int16 coefficients of one frame -> the reference's int_buffer layout of component k
 static void coefs_to_reference_layout(const JhGeom &g, const int16_t *fc, int k, int32_t *out)
 {
@@ -321,6 +340,13 @@ static int parse_frame(const uint8_t *p, size_t n, JhHeader *h, std::vector<Scan
 		sd.Ri = h->g.Ri;
 		scans->push_back(sd);
 	};
+	if (h->Ns == 0) {
+		// no scan at all: the frame of zero coefficients (mid grey), as the reference writes it
+		for (int j = 0; j < h->g.ncomp; ++j) {
+			h->g.scan_order[j] = j;
+		}
+		return RET_SUCCESS;
+	}
 	if (h->Ns == h->g.ncomp) {
 		// one scan with every component: the device finds its end (no host pass over the data)
 		for (int j = 0; j < h->Ns; ++j) {
@@ -756,7 +782,7 @@ __global__ void k_dec_init(JhDecState *st, int n)
 static int decoder_launch(jpeg_hip_decoder *dec, hipStream_t s)
 {
 	const JhTimerHook th = dec->timer.hook();
-	if (dec->pass.size() > 1 || dec->pass[0].comp != -1) {
+	if (dec->pass.size() != 1 || dec->pass[0].comp != -1) {
 		// scans of single components: blocks no scan reaches stay zero (common.c:129)
 		if (hipMemsetAsync(dec->d_coefs, 0, (size_t)dec->nframes * dec->g.nblk * 64 * sizeof(int16_t), s) != hipSuccess) {
 			return RET_FAILURE_LOGIC_ERROR;
@@ -784,7 +810,7 @@ static int decoder_launch(jpeg_hip_decoder *dec, hipStream_t s)
 
 extern "C" int jpeg_hip_decoder_run(jpeg_hip_decoder *dec, void *d_samples, size_t frame_stride, void *stream)
 {
-	if (!dec || dec->nframes == 0 || dec->pass.empty() || !d_samples) {
+	if (!dec || dec->nframes == 0 || !d_samples) {
 		return RET_FAILURE_LOGIC_ERROR;
 	}
 	if (frame_stride < jpeg_hip_decoder_frame_bytes(dec)) {

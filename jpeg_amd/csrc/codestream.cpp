@@ -298,6 +298,9 @@ int jh_finish_geometry(JhGeom *g)
 		// Ns == 1 walk: plain raster over the padded block grid (decoder.c:285-289); same
 		// result as H = V = 1 over that grid.
 		const int H = g->H[0], V = g->V[0];
+		if (H < 1 || H > 4 || V < 1 || V > 4) {
+			return RET_FAILURE_FILE_UNSUPPORTED;               // the reference divides by zero (common.c:171-172)
+		}
 		const int m_x = (g->X + 8 * H - 1) / (8 * H), m_y = (g->Y + 8 * V - 1) / (8 * V);
 		g->H[0] = g->V[0] = 1;
 		g->max_H = g->max_V = 1;
@@ -613,8 +616,11 @@ static int parse_segments(Reader &r, JhHeader *h, bool *eoi)
 			}
 			r.pos += 2;
 			h->Ns = (int)r.u8();
-			if (h->Ns < 1 || h->Ns > JH_MAX_COMP || !r.ok(2 * (size_t)h->Ns + 3)) {
+			if (h->Ns < 1 || h->Ns > JH_MAX_COMP) {
 				return RET_FAILURE_FILE_UNSUPPORTED;
+			}
+			if (!r.ok(2 * (size_t)h->Ns + 3)) {
+				return RET_FAILURE_FILE_IO;                        // cut inside the scan header: read_byte() fails
 			}
 			for (int j = 0; j < h->Ns; ++j) {
 				const int cs = (int)r.u8();
@@ -644,7 +650,14 @@ static int parse_segments(Reader &r, JhHeader *h, bool *eoi)
 				*eoi = true;
 				return RET_SUCCESS;
 			}
-			return RET_FAILURE_FILE_UNSUPPORTED;               // EOI before any scan: nothing to decode here
+			if (have_sof) {
+				// EOI before any scan: the reference's epilogue() makes an image of the zero coefficients
+				// alloc_buffers() left (decoder.c:603-612, common.c:129).  Ns = 0 tells the caller.
+				h->Ns = 0;
+				h->ecs_offset = r.pos;
+				return RET_SUCCESS;
+			}
+			return RET_FAILURE_FILE_UNSUPPORTED;               // and no frame header either: nothing to make an image of
 		}
 		return RET_FAILURE_FILE_UNSUPPORTED;                   // decoder.c:654-656
 	}

@@ -141,6 +141,22 @@ def test_restart_streams_from_the_oracle_extension(hip, oracle):
         assert np.array_equal(outs[0], oracle.decode(jpg)[1])
 
 
+def test_frame_without_a_scan(hip, oracle):
+    """EOI right behind the headers: the reference's epilogue() runs on the zero coefficients alloc_buffers()
+    left (decoder.c:603-612, common.c:129) and writes a mid-grey image; so does this path."""
+    img = synth_image(120, 72, 3, 8, seed=12)
+    _, jpg, _ = oracle.encode(img, P=8, H=2, V=2, q=80, optimize=1)
+    bare = jpg[:jpg.index(b"\xff\xda")] + b"\xff\xd9"
+    err, opx, _ = oracle.decode(bare)
+    assert err == 0
+    outs, st = hip.decode([bare, bare])
+    assert st == [0, 0]
+    assert np.array_equal(outs[0], opx) and np.array_equal(outs[1], opx)
+    # in one batch with frames that do have a scan: the odd one out is refused, the others decode
+    outs, st = hip.decode([jpg, bare])
+    assert st == [0, 0x1001] and np.array_equal(outs[0], oracle.decode(jpg)[1])
+
+
 def test_restart_markers_the_header_does_not_announce(hip, oracle):
     """The reference never looks at Ri (quirk Q1, decoder.c:622-633): the markers decide.  A stream whose DRI
     is missing, or promises far fewer markers than come, decodes all the same (the segment tables are sized
