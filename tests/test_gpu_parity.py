@@ -141,6 +141,55 @@ def test_restart_streams_from_the_oracle_extension(hip, oracle):
         assert np.array_equal(outs[0], oracle.decode(jpg)[1])
 
 
+def _dqt16(jpg, scale):
+    """Rewrite every 8-bit DQT segment as a 16-bit one (Pq = 1) with the values scaled."""
+    out, i = bytearray(jpg[:2]), 2
+    while jpg[i + 1] != 0xDA:
+        n = (jpg[i + 2] << 8) | jpg[i + 3]
+        if jpg[i + 1] == 0xDB and n == 67 and (jpg[i + 4] >> 4) == 0:
+            out += b"\xff\xdb\x00\x83" + bytes([0x10 | jpg[i + 4]])
+            for v in jpg[i + 5:i + 69]:
+                out += int(min(65535, v * scale)).to_bytes(2, "big")
+        else:
+            out += jpg[i:i + 2 + n]
+        i += 2 + n
+    return bytes(out + jpg[i:])
+
+
+def test_quantisation_tables_of_16_bits_and_table_selectors(hip, oracle):
+    """What the reference decoder takes beyond what its encoder writes (quirk Q4): DQT with Pq = 1 (entries
+    far above 255: the product with the coefficient no longer fits 24 bits and the int -> float conversion of
+    dequantize_block() rounds, imgproc.c:10-19), several tables in one DQT / DHT segment, SOF1."""
+    img = synth_image(200, 136, 3, 8, seed=14)
+    _, jpg, _ = oracle.encode(img, P=8, H=2, V=1, q=60, optimize=1)
+    for scale in (1, 37, 700, 4000):
+        wide = _dqt16(jpg, scale)
+        err, opx, oinfo = oracle.decode(wide)
+        assert err == 0 and int(oinfo.qtables.max()) == min(65535, int(oracle.decode(jpg)[2].qtables.max()) * scale)
+        d = hip.Decoder()
+        d.prepare([wide])
+        out = d.run()
+        assert d.sync() == [0]
+        _assert_coefs(d.coefficients(0), oinfo)
+        assert np.array_equal(d.to_arrays(out)[0], opx), scale
+        d.close()
+    # both DQT tables in ONE segment, all four DHT tables in ONE segment, SOF1 instead of SOF0
+    segs, i = [], 2
+    while jpg[i + 1] != 0xDA:
+        n = (jpg[i + 2] << 8) | jpg[i + 3]
+        segs.append((jpg[i + 1], jpg[i + 4:i + 2 + n]))
+        i += 2 + n
+    dqt = b"".join(b for m, b in segs if m == 0xDB)
+    dht = b"".join(b for m, b in segs if m == 0xC4)
+    sof = [b for m, b in segs if m == 0xC0][0]
+    merged = (jpg[:2] + b"\xff\xdb" + (len(dqt) + 2).to_bytes(2, "big") + dqt + b"\xff\xc1" + (len(sof) + 2).to_bytes(2, "big") + sof +
+              b"\xff\xc4" + (len(dht) + 2).to_bytes(2, "big") + dht + jpg[i:])
+    err, opx, _ = oracle.decode(merged)
+    assert err == 0 and np.array_equal(opx, oracle.decode(jpg)[1])
+    outs, st = hip.decode([merged])
+    assert st == [0] and np.array_equal(outs[0], opx)
+
+
 def test_frame_without_a_scan(hip, oracle):
     """EOI right behind the headers: the reference's epilogue() runs on the zero coefficients alloc_buffers()
     left (decoder.c:603-612, common.c:129) and writes a mid-grey image; so does this path."""
