@@ -1371,7 +1371,7 @@ static bool reference_layout_to_coefs(const JhGeom &g, int k, const int32_t *in,
 static int geom_from_desc(const jpeg_hip_frame_desc *fd, JhGeom *g)
 {
 	memset(g, 0, sizeof *g);
-	if (!fd || fd->Nf < 1 || fd->Nf > JH_MAX_COMP || fd->X <= 0 || fd->Y <= 0 || fd->X > 65535 || fd->Y > 65535) {
+	if (!fd || fd->Nf < 1 || fd->Nf > JH_MAX_COMP || fd->Nf == 2 || fd->X <= 0 || fd->Y <= 0 || fd->X > 65535 || fd->Y > 65535) {
 		return RET_FAILURE_FILE_UNSUPPORTED;
 	}
 	g->P = fd->P; g->X = fd->X; g->Y = fd->Y; g->Nf = fd->Nf; g->ncomp = fd->Nf;
@@ -1404,6 +1404,9 @@ extern "C" int jpeg_hip_read_scan(int device, const jpeg_hip_frame_desc *frame, 
 	}
 	if (!frame || !scan || !dc || !ac || !ecs || !coef) {
 		return RET_FAILURE_LOGIC_ERROR;
+	}
+	if (consumed) {
+		*consumed = 0;
 	}
 	JhHeader h;
 	memset(&h, 0, sizeof h);

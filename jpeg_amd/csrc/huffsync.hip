@@ -42,7 +42,8 @@
 
 #define KMAX JH_CHAIN_MAX
 #define OWN JH_SEQ_OWN
-#define DIRN 4                          // distinct exit states remembered per sub-sequence
+#define DIRN 2                          // distinct exit states remembered per sub-sequence (4 buys nothing measurable
+                                        // and costs the LDS of a fifth workgroup per CU)
 #define NONE16 0xffffu
 #define META_RESTART 0x80000000u
 #define JH_WALK_ROUNDS 12                // a walk that changes a workgroup's last record sends its successor round again
@@ -254,13 +255,28 @@ __global__ __launch_bounds__(256) void k_huff_chains(const HuffArgs a)
 	unsigned char *luts = smem;
 	uint32_t *sw = reinterpret_cast<uint32_t *>(smem + sizeof(JhHuffLut) * a.w.max_luts);
 	__shared__ DecTables tb;
-	__shared__ int dcs[JH_MAX_COMP][256];
-	__shared__ unsigned long long dkey[256][DIRN];
-	__shared__ uint16_t downer[256][DIRN];
-	__shared__ uint8_t dcnt[256];
-	__shared__ unsigned long long cstate[256];
-	__shared__ uint32_t cseg[256];
-	__shared__ uint16_t alive[2][256];
+	// LDS decides how many workgroups share a CU, and this kernel's time follows the number of waves in flight
+	// (measured: 12 instead of 16 waves per CU cost 21 %): the arrays of the chain steps and the path records of
+	// the emission, which never live at the same time, share one piece of it.  31 KB with four tables: 5
+	// workgroups = 20 waves per CU.
+	enum {
+		OFF_DCS = 0,                                       // int [JH_MAX_COMP][256]
+		OFF_DKEY = OFF_DCS + JH_MAX_COMP * 256 * 4,        // u64 [256][DIRN]
+		OFF_DOWNER = OFF_DKEY + 256 * DIRN * 8,            // u16 [256][DIRN]
+		OFF_CSTATE = OFF_DOWNER + 256 * DIRN * 2,          // u64 [256]
+		OFF_CSEG = OFF_CSTATE + 256 * 8,                   // u32 [256]
+		OFF_ALIVE = OFF_CSEG + 256 * 4,                    // u16 [2][256]
+		OFF_DCNT = OFF_ALIVE + 2 * 256 * 2,                // u8 [256]
+		WORK_BYTES = OFF_DCNT + 256
+	};
+	__shared__ __align__(16) unsigned char work[WORK_BYTES];
+	int (*dcs)[256] = reinterpret_cast<int (*)[256]>(work + OFF_DCS);
+	unsigned long long (*dkey)[DIRN] = reinterpret_cast<unsigned long long (*)[DIRN]>(work + OFF_DKEY);
+	uint16_t (*downer)[DIRN] = reinterpret_cast<uint16_t (*)[DIRN]>(work + OFF_DOWNER);
+	unsigned long long *cstate = reinterpret_cast<unsigned long long *>(work + OFF_CSTATE);
+	uint32_t *cseg = reinterpret_cast<uint32_t *>(work + OFF_CSEG);
+	uint16_t (*alive)[256] = reinterpret_cast<uint16_t (*)[256]>(work + OFF_ALIVE);
+	uint8_t *dcnt = work + OFF_DCNT;
 	__shared__ int nalive[2];
 	__shared__ PathLds P;
 
@@ -401,10 +417,10 @@ __global__ __launch_bounds__(256) void k_huff_chains(const HuffArgs a)
 	}
 
 	// ---- emit from the path of the first chain ---------------------------------------------------
-	static_assert(sizeof(dkey) >= 256 * sizeof(JhSubInfo), "the path records reuse the directory's LDS");
+	static_assert(WORK_BYTES >= 256 * sizeof(JhSubInfo), "the path records reuse the LDS of the chain steps");
 	const int lo = b == 0 ? 0 : KMAX, hi = range_len - 1;
 	if (tid == 0) {
-		P.trec = reinterpret_cast<JhSubInfo *>(&dkey[0][0]);
+		P.trec = reinterpret_cast<JhSubInfo *>(work);
 		P.gap = 0;
 	}
 	P.cov[tid] = 0;
