@@ -280,7 +280,8 @@ int jh_launch_ecs_unstuff(const JhDecodeWork &w, hipStream_t s, const JhTimerHoo
 // belongs to the thread in whose sub-sequence it STARTS: that thread decodes on past its boundary
 // until the block is complete, the next thread discards what it decodes before its first block start.
 
-#define WR_THREADS 256
+#define WR_THREADS 448                 // 144 B of LDS per thread + the tables once per workgroup: two workgroups of 7 waves
+                                       // fill a CU's 160 KB (14 waves; 256 threads gave 12 and 1.22 against 1.16 ms)
 
 // chains workgroup that emitted the entry record of sub-sequence t (huffsync.hip)
 __device__ __forceinline__ uint32_t chain_wg_of(uint32_t t)

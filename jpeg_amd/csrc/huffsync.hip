@@ -43,7 +43,8 @@
 #define KMAX JH_CHAIN_MAX
 #define OWN JH_SEQ_OWN
 #define DIRN 2                          // distinct exit states remembered per sub-sequence (4 buys nothing measurable
-                                        // and costs the LDS of a fifth workgroup per CU)
+                                        // and costs the LDS of a fifth workgroup per CU; 1 would make room for a sixth,
+                                        // but the chains that then miss each other cost more: 1.46 against 1.41 ms)
 #define NONE16 0xffffu
 #define META_RESTART 0x80000000u
 #define JH_WALK_ROUNDS 12                // a walk that changes a workgroup's last record sends its successor round again
@@ -179,42 +180,45 @@ __device__ __forceinline__ Agg agg_of(const JhSubInfo &r)
 
 #define REC_INVALID (1ull << 63)        // JhSubInfo.state: no record (the workgroup's path does not reach here)
 
-struct PathLds {
+struct PathLds {                      // written while the chains walk, read by the emission
 	uint16_t succ[256];               // chain this chain merged into (local index), NONE16 = none
 	uint8_t nst[256];                 // steps walked: the chain covers local sub-sequences [i, i + nst]
 	uint8_t dflag[256];               // its link is a restart link (garbage before it)
+	Agg scratch[4];
+	int gap;
+};
+
+struct PathWork {                     // emission only: lives where the arrays of the chain steps were
+	JhSubInfo trec[256];              // records of the marked path, by local sub-sequence
 	uint16_t reach[2][256];
 	uint8_t mark[256];
 	uint16_t pred[256];
 	uint8_t cov[256];
-	JhSubInfo *trec;                  // records of the marked path, by local sub-sequence (256 entries of LDS)
-	Agg scratch[4];
-	int gap;
 };
 
 // marks the chains on the path that starts with chain `seed`; pred[] = predecessor on the path.
 // A restart link that ends at or after local sub-sequence `trust` is not followed: from there on the
 // path claims to be the true parse, and a fresh guess is not.
-__device__ __forceinline__ void mark_path(PathLds &L, int seed, int trust)
+__device__ __forceinline__ void mark_path(const PathLds &L, PathWork &W, int seed, int trust)
 {
 	const int tid = threadIdx.x;
 	const bool cut = L.dflag[tid] && tid + (int)L.nst[tid] >= trust;
-	L.reach[0][tid] = cut ? (uint16_t)NONE16 : L.succ[tid];
-	L.mark[tid] = tid == seed ? 1 : 0;
-	L.pred[tid] = NONE16;
+	W.reach[0][tid] = cut ? (uint16_t)NONE16 : L.succ[tid];
+	W.mark[tid] = tid == seed ? 1 : 0;
+	W.pred[tid] = NONE16;
 	__syncthreads();
 	int rb = 0;
 	for (int k = 0; k < 8; ++k) {
-		const unsigned r = L.reach[rb][tid];
-		if (L.mark[tid] && r != NONE16) {
-			L.mark[r] = 1;
+		const unsigned r = W.reach[rb][tid];
+		if (W.mark[tid] && r != NONE16) {
+			W.mark[r] = 1;
 		}
-		L.reach[rb ^ 1][tid] = r != NONE16 ? L.reach[rb][r] : (uint16_t)NONE16;
+		W.reach[rb ^ 1][tid] = r != NONE16 ? W.reach[rb][r] : (uint16_t)NONE16;
 		__syncthreads();
 		rb ^= 1;
 	}
-	if (L.mark[tid] && L.succ[tid] != NONE16 && !cut) {
-		L.pred[L.succ[tid]] = (uint16_t)tid;
+	if (W.mark[tid] && L.succ[tid] != NONE16 && !cut) {
+		W.pred[L.succ[tid]] = (uint16_t)tid;
 	}
 	__syncthreads();
 }
@@ -257,7 +261,7 @@ __global__ __launch_bounds__(256) void k_huff_chains(const HuffArgs a)
 	__shared__ DecTables tb;
 	// LDS decides how many workgroups share a CU, and this kernel's time follows the number of waves in flight
 	// (measured: 12 instead of 16 waves per CU cost 21 %): the arrays of the chain steps and the path records of
-	// the emission, which never live at the same time, share one piece of it.  31 KB with four tables: 5
+	// the emission, which never live at the same time, share one piece of it.  29 KB with four tables: 5
 	// workgroups = 20 waves per CU.
 	enum {
 		OFF_DCS = 0,                                       // int [JH_MAX_COMP][256]
@@ -267,7 +271,8 @@ __global__ __launch_bounds__(256) void k_huff_chains(const HuffArgs a)
 		OFF_CSEG = OFF_CSTATE + 256 * 8,                   // u32 [256]
 		OFF_ALIVE = OFF_CSEG + 256 * 4,                    // u16 [2][256]
 		OFF_DCNT = OFF_ALIVE + 2 * 256 * 2,                // u8 [256]
-		WORK_BYTES = OFF_DCNT + 256
+		STEP_BYTES = OFF_DCNT + 256,
+		WORK_BYTES = STEP_BYTES > (int)sizeof(PathWork) ? STEP_BYTES : (int)sizeof(PathWork)
 	};
 	__shared__ __align__(16) unsigned char work[WORK_BYTES];
 	int (*dcs)[256] = reinterpret_cast<int (*)[256]>(work + OFF_DCS);
@@ -417,46 +422,45 @@ __global__ __launch_bounds__(256) void k_huff_chains(const HuffArgs a)
 	}
 
 	// ---- emit from the path of the first chain ---------------------------------------------------
-	static_assert(WORK_BYTES >= 256 * sizeof(JhSubInfo), "the path records reuse the LDS of the chain steps");
+	PathWork &W = *reinterpret_cast<PathWork *>(work);      // the arrays of the chain steps are dead from here on
 	const int lo = b == 0 ? 0 : KMAX, hi = range_len - 1;
 	if (tid == 0) {
-		P.trec = reinterpret_cast<JhSubInfo *>(work);
 		P.gap = 0;
 	}
-	P.cov[tid] = 0;
-	mark_path(P, 0, lo - 1);
-	if (P.mark[tid] && tid < range_len) {
-		const int from = tid == 0 ? 0 : (int)P.pred[tid] + (int)P.nst[P.pred[tid]] + 1;
+	W.cov[tid] = 0;
+	mark_path(P, W, 0, lo - 1);
+	if (W.mark[tid] && tid < range_len) {
+		const int from = tid == 0 ? 0 : (int)W.pred[tid] + (int)P.nst[W.pred[tid]] + 1;
 		const int to = tid + (int)P.nst[tid];
 		for (int jl = from; jl <= min(to, hi); ++jl) {
-			P.trec[jl] = rec[(size_t)tid * (KMAX + 1) + (jl - tid)];
-			P.cov[jl] = 1;
+			W.trec[jl] = rec[(size_t)tid * (KMAX + 1) + (jl - tid)];
+			W.cov[jl] = 1;
 		}
 	}
 	__syncthreads();
 	const bool mine = tid >= lo && tid <= hi;
-	if (mine && !P.cov[tid]) {
+	if (mine && !W.cov[tid]) {
 		P.gap = 1;                         // a chain on the path was cut, or the true parse ran into garbage
 	}
 	__syncthreads();
 	const bool gap = P.gap != 0;
 	JhSubInfo *prec = w.prec + fr.sub_off + j0;
 	if (mine) {
-		JhSubInfo r = P.trec[tid];
-		if (!P.cov[tid]) {
+		JhSubInfo r = W.trec[tid];
+		if (!W.cov[tid]) {
 			r.state = REC_INVALID;
 		}
 		prec[tid] = r;
 	}
 	Agg v = agg_identity();
 	if (mine && !gap) {
-		v = agg_of(P.trec[tid]);
+		v = agg_of(W.trec[tid]);
 	}
 	Agg incl, excl;
 	block_seg_scan(v, P.scratch, incl, excl);
 	if (mine && !gap) {
 		const bool first = tid == 0;       // only in the frame's first workgroup: a DC code of block 0 starts at bit 0
-		w.start[fr.sub_off + j0 + tid] = make_start(excl, first ? 0ull : P.trec[tid - 1].state, first ? 0u : P.trec[tid - 1].seg);
+		w.start[fr.sub_off + j0 + tid] = make_start(excl, first ? 0ull : W.trec[tid - 1].state, first ? 0u : W.trec[tid - 1].seg);
 	}
 	if (tid == 255) {
 		store_agg(&w.wg_agg[fr.wg_off + b], incl, gap ? (uint32_t)JH_AGG_GAP : 0u);
@@ -465,8 +469,8 @@ __global__ __launch_bounds__(256) void k_huff_chains(const HuffArgs a)
 		// the state this workgroup ASSUMED at its first emitted sub-sequence; the walk kernel compares it
 		// with what the predecessor says
 		unsigned long long key = REC_INVALID;
-		if (b > 0 && P.cov[lo - 1]) {
-			key = chain_key(P.trec[lo - 1].state, P.trec[lo - 1].seg);
+		if (b > 0 && W.cov[lo - 1]) {
+			key = chain_key(W.trec[lo - 1].state, W.trec[lo - 1].seg);
 		}
 		if ((w.debug & 1) && (b & 1)) {
 			key = REC_INVALID;                 // test hook: make every other workgroup take the walk
