@@ -76,24 +76,48 @@ def decode_stream(frames, batch=256, device=0):
     tensor of a batch stays valid until the batch after the next one has been yielded."""
     from concurrent.futures import ThreadPoolExecutor
     torch = binding._torch()
-    decs = [binding.Decoder(device), binding.Decoder(device)]
-    stream = torch.cuda.Stream(device=device)
+    decs, stream = _stream_decoders(device)
     chunks = [frames[i:i + batch] for i in range(0, len(frames), batch)]
-    try:
-        with ThreadPoolExecutor(max_workers=1) as pool:
-            fut = pool.submit(decs[0].prepare, chunks[0]) if chunks else None
+    with ThreadPoolExecutor(max_workers=1) as pool:
+        fut = pool.submit(decs[0].prepare, chunks[0]) if chunks else None
+        try:
             for i in range(len(chunks)):
                 fut.result()
                 d = decs[i & 1]
-                if i + 1 < len(chunks):
-                    fut = pool.submit(decs[(i + 1) & 1].prepare, chunks[i + 1])
+                fut = pool.submit(decs[(i + 1) & 1].prepare, chunks[i + 1]) if i + 1 < len(chunks) else None
                 with torch.cuda.stream(stream):
                     out = d.run()
                 st = d.sync()
                 yield out, st
-    finally:
+        finally:
+            if fut is not None:
+                try:
+                    fut.result()                   # a consumer that stops early: let the helper finish its batch
+                except binding.JpegError:
+                    pass
+
+
+_stream_state = {}
+
+
+def _stream_decoders(device):
+    """The two decoder objects and the stream of decode_stream(), kept between calls: their pinned staging
+    buffers and device workspaces only grow, and making them anew costs more than decoding a few thousand
+    frames (hipHostMalloc of 150 MB pins every page).  release_stream_decoders() frees them."""
+    if device not in _stream_state:
+        torch = binding._torch()
+        if not _stream_state:
+            import atexit
+            atexit.register(release_stream_decoders)   # while the HIP runtime is still there
+        _stream_state[device] = ([binding.Decoder(device), binding.Decoder(device)], torch.cuda.Stream(device=device))
+    return _stream_state[device]
+
+
+def release_stream_decoders():
+    for decs, _ in _stream_state.values():
         for d in decs:
             d.close()
+    _stream_state.clear()
 
 
 def gather_stats(local, dist=None):
