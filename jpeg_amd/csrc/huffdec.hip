@@ -280,8 +280,11 @@ int jh_launch_ecs_unstuff(const JhDecodeWork &w, hipStream_t s, const JhTimerHoo
 // belongs to the thread in whose sub-sequence it STARTS: that thread decodes on past its boundary
 // until the block is complete, the next thread discards what it decodes before its first block start.
 
-#define WR_THREADS 448                 // 144 B of LDS per thread + the tables once per workgroup: two workgroups of 7 waves
-                                       // fill a CU's 160 KB (14 waves; 256 threads gave 12 and 1.22 against 1.16 ms)
+#define WR_THREADS 256                 // 144 B of LDS per thread + the tables once per workgroup: 3 workgroups = 12 waves
+                                       // per CU.  448 threads (2 x 7 waves fill the CU's LDS) decode 3 % faster when the
+                                       // decoder has the GPU to itself, but a step that encodes at the same time loses 5 %:
+                                       // the encoder's workgroups then find no LDS beside them (bench `value` 80.3 against
+                                       // 84.2 Gpix/s; 128 / 192 / 320 threads: 79.7 / 82.6 / 77.7)
 
 // chains workgroup that emitted the entry record of sub-sequence t (huffsync.hip)
 __device__ __forceinline__ uint32_t chain_wg_of(uint32_t t)
