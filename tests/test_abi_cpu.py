@@ -67,3 +67,23 @@ def test_fails_loudly_without_gpu(built_lib):
     assert built_lib.write_scan(fd, sd, tabs, tabs, 1, [np.zeros((4, 64), np.int32)])[0] == built_lib.RET_FAILURE_LOGIC_ERROR
     # the drop-in entry points refuse too (no silent CPU path)
     assert L.jpeg_hip_process_jpeg_file(b"/nonexistent.jpg", None) == 0x1002  # RET_FAILURE_FILE_OPEN first
+
+
+def test_header_is_plain_c99_and_links(built_lib, tmp_path):
+    """include/jpeg_amd.h through a C compiler in strict C99 mode, linked against the library, run on the host:
+    what a maintainer of the reference (C99, no C++) does first."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc here")
+    exe = str(tmp_path / "info")
+    libdir = os.path.dirname(built_lib.LIB_PATH)
+    subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "examples", "info.c"), "-L" + libdir, "-ljpeg_amd", "-Wl,-rpath," + libdir,
+                    "-o", exe], check=True, timeout=120)
+    r = subprocess.run([exe, os.path.join(ROOT, "tests", "golden", "d_pil_422_jfif.jpg")], capture_output=True,
+                       text=True, timeout=60)
+    assert r.returncode == 0 and "112x80 P=8 Nf=3" in r.stdout and "[id 1 2x1 Tq 0]" in r.stdout
+    r = subprocess.run([exe, os.path.join(ROOT, "tests", "golden", "d_pil_progressive.jpg")], capture_output=True,
+                       text=True, timeout=60)
+    assert r.returncode == 1 and "RET 0x1001" in r.stdout
