@@ -1006,6 +1006,7 @@ struct jpeg_hip_encoder {
 	JhEncodeWork work;
 	hipStream_t last_stream = nullptr;
 	bool ran = false;
+	long long alloc_sig[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // what the device buffers were sized for
 	StageTimer timer;
 
 	void release()
@@ -1080,8 +1081,11 @@ static int encoder_configure(jpeg_hip_encoder *enc, int nframes, int X, int Y, i
 		return RET_FAILURE_LOGIC_ERROR;
 	}
 	HIPCHK(hipSetDevice(enc->device));
-	enc->release();
+	if (enc->ran) {
+		HIPCHK(hipStreamSynchronize(enc->last_stream));    // the buffers are about to be reused
+	}
 	enc->ran = false;
+	enc->nframes = 0;                                      // not configured until everything below has succeeded
 	if ((Nf != 1 && Nf != 3) || X <= 0 || Y <= 0 || X > 65535 || Y > 65535) {
 		return RET_FAILURE_FILE_UNSUPPORTED;               // encoder.c:147-148
 	}
@@ -1092,7 +1096,6 @@ static int encoder_configure(jpeg_hip_encoder *enc, int nframes, int X, int Y, i
 		return RET_FAILURE_FILE_UNSUPPORTED;               // DRI holds 16 bits (extension: the reference writes none)
 	}
 	enc->prm = *params;
-	enc->nframes = nframes;
 	JhGeom &g = enc->g;
 	memset(&g, 0, sizeof g);
 	g.P = P; g.X = X; g.Y = Y; g.Nf = Nf; g.ncomp = Nf;
@@ -1139,6 +1142,13 @@ static int encoder_configure(jpeg_hip_encoder *enc, int nframes, int X, int Y, i
 	w.restart_interval = params->restart_interval;
 	w.nivl = w.restart_interval > 0 ? (g.nmcu + w.restart_interval - 1) / w.restart_interval : 0;
 
+	// Everything below is sized by (frames, geometry, restart interval): a configure() that changes only the
+	// quality, the table mode or nothing at all (a service that reconfigures per batch) keeps the buffers.
+	const long long sig[8] = {nframes, X, Y, Nf, P, g.H[0], g.V[0], w.restart_interval};
+	const bool keep = enc->d_out != nullptr && memcmp(sig, enc->alloc_sig, sizeof sig) == 0;
+	if (!keep) {
+	enc->release();
+	memset(enc->alloc_sig, 0, sizeof enc->alloc_sig);      // set again once every buffer is there
 	HIPCHK(hipMalloc((void **)&enc->d_quant, nframes * sizeof(JhQuant)));
 	HIPCHK(hipMalloc((void **)&enc->d_coefs, (size_t)nframes * g.nblk * 64 * sizeof(int16_t)));
 	HIPCHK(hipMalloc((void **)&enc->d_codes, (size_t)nframes * 4 * sizeof(JhHuffEnc)));
@@ -1154,6 +1164,10 @@ static int encoder_configure(jpeg_hip_encoder *enc, int nframes, int X, int Y, i
 		HIPCHK(hipMalloc((void **)&enc->d_ivl_raw, (size_t)nframes * w.nivl * sizeof(uint32_t)));
 		HIPCHK(hipMalloc((void **)&enc->d_ivl_padsum, (size_t)nframes * (w.nivl + 1) * sizeof(uint32_t)));
 		HIPCHK(hipMalloc((void **)&enc->d_ivl_eb, (size_t)nframes * w.nivl * sizeof(uint32_t)));
+	}
+	HIPCHK(hipMalloc((void **)&enc->d_hdr_parts, 4096));
+	HIPCHK(hipMalloc((void **)&enc->d_specs, (size_t)nframes * 4 * sizeof(JhDevSpec)));
+	memcpy(enc->alloc_sig, sig, sizeof sig);
 	}
 	{
 		// the header bytes in front of the DHT segments and behind them do not depend on the tables
@@ -1171,10 +1185,9 @@ static int encoder_configure(jpeg_hip_encoder *enc, int nframes, int X, int Y, i
 			}
 			pos += 2 + (((size_t)full[pos + 2] << 8) | full[pos + 3]);
 		}
-		if (pre == 0 || suf == 0) {
+		if (pre == 0 || suf == 0 || full.size() > 4096) {
 			return RET_FAILURE_LOGIC_ERROR;
 		}
-		HIPCHK(hipMalloc((void **)&enc->d_hdr_parts, full.size()));
 		HIPCHK(hipMemcpy(enc->d_hdr_parts, full.data(), pre, hipMemcpyHostToDevice));
 		HIPCHK(hipMemcpy(enc->d_hdr_parts + pre, full.data() + suf, full.size() - suf, hipMemcpyHostToDevice));
 		w.hdr_pre = enc->d_hdr_parts;
@@ -1182,7 +1195,6 @@ static int encoder_configure(jpeg_hip_encoder *enc, int nframes, int X, int Y, i
 		w.hdr_suf = enc->d_hdr_parts + pre;
 		w.hdr_suf_len = (int)(full.size() - suf);
 		w.ntab = g.Nf > 1 ? 2 : 1;
-		HIPCHK(hipMalloc((void **)&enc->d_specs, (size_t)nframes * 4 * sizeof(JhDevSpec)));
 		HIPCHK(hipMemset(enc->d_specs, 0, (size_t)nframes * 4 * sizeof(JhDevSpec)));
 		w.specs = enc->d_specs;
 	}
@@ -1209,7 +1221,11 @@ static int encoder_configure(jpeg_hip_encoder *enc, int nframes, int X, int Y, i
 	enc->hdr_len.assign(nframes, 0);
 	enc->state.assign(nframes, JhEncState());
 	// default tables + headers for every frame (the optimised path overwrites them per run)
-	return upload_codes_and_headers(enc, 0, nframes, nullptr);
+	err = upload_codes_and_headers(enc, 0, nframes, nullptr);
+	if (!err) {
+		enc->nframes = nframes;
+	}
+	return err;
 }
 
 extern "C" int jpeg_hip_encoder_configure(jpeg_hip_encoder *enc, int nframes, int X, int Y, int Nf, int P,

@@ -190,6 +190,30 @@ def test_quantisation_tables_of_16_bits_and_table_selectors(hip, oracle):
     assert st == [0] and np.array_equal(outs[0], opx)
 
 
+def test_one_encoder_object_configured_again_and_again(hip, oracle):
+    """configure() keeps the device buffers while their sizes stay the same (quality and table mode may change),
+    sizes them anew when the batch or the geometry changes, and a refused configure() leaves the object
+    unconfigured: every run must give the oracle's bytes."""
+    e = hip.Encoder()
+    imgs = [synth_image(200, 120, 3, 8, seed=80 + i) for i in range(3)]
+    small = [synth_image(64, 40, 1, 8, seed=85)]
+    for (batch, H, V, q, opt, ri) in [(imgs, 2, 2, 70, 1, 0), (imgs, 2, 2, 95, 0, 0), (imgs, 2, 2, 30, 1, 0),
+                                       (imgs[:2], 2, 2, 30, 1, 0), (imgs, 2, 1, 80, 1, 0), (imgs, 2, 1, 80, 1, 4),
+                                       (small, 1, 1, 85, 0, 0), (imgs, 2, 2, 70, 1, 0)]:
+        a0 = batch[0]
+        e.configure(len(batch), a0.shape[1], a0.shape[0], 1 if a0.ndim == 2 else 3, 8, H, V, q, opt, ri)
+        e.run(e.upload(batch))
+        st, ln = e.sync()
+        assert st == [0] * len(batch)
+        for f, im in enumerate(batch):
+            assert e.jpeg(f, ln[f]) == oracle.encode(im, P=8, H=H, V=V, q=q, optimize=opt, restart_interval=ri)[1]
+    with pytest.raises(hip.JpegError):
+        e.configure(3, 200, 120, 2, 8, 1, 1, 70, 1, 0)       # two components: refused (encoder.c:147-148)
+    with pytest.raises(hip.JpegError):
+        e.run(e.upload(imgs))                                # ... and the object is not usable until configured
+    e.close()
+
+
 def test_frame_without_a_scan(hip, oracle):
     """EOI right behind the headers: the reference's epilogue() runs on the zero coefficients alloc_buffers()
     left (decoder.c:603-612, common.c:129) and writes a mid-grey image; so does this path."""
