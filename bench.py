@@ -253,7 +253,9 @@ def main():
         "metric": "Mpix/s decode+encode, 4K 4:2:0 q90 (every pixel is decoded AND encoded once per step)",
         "value": round(value, 1), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(t / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32+f64 pixel maths (bit-exact), u8/int16 entropy coding", "data": "synthetic",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "dtype_detail": "pixel kernels: binary32 DCT / quantisation and binary64 colour maths, bit-exact with the reference; "
+                        "entropy kernels: u8 / int16 / u32 integer work",
         "config": {"workload": "metric_4k_420_q90: 3840x2160 8-bit 4:2:0 q90, default Huffman tables, no restart markers",
                    "frames_per_gpu_per_step": F, "parallelism": "frames sharded over %d GPU(s), no collectives" % world},
         "decode_mpix_s": round(world * F * pix * args.steps / t_d / 1e6, 1),
