@@ -34,7 +34,10 @@
 extern "C" {
 #endif
 
-/* ---- error codes: identical values to the reference (common.h:15-31) ------------------ */
+/* ---- error codes: identical values to the reference (common.h:15-31) ------------------
+ * A translation unit of the reference that includes its own common.h first (integration/ref_glue.c)
+ * already has them. */
+#ifndef JPEG_COMMON_H
 enum {
 	RET_SUCCESS                   = 0x0000,
 	RET_FAILURE_FILE_IO           = 0x1000,
@@ -46,6 +49,7 @@ enum {
 	RET_FAILURE_OVERFLOW_ERROR    = 0x3001,
 	RET_FAILURE_NO_MORE_DATA      = 0x4000
 };
+#endif
 /* device-side conditions for which the reference assert()s or returns -1:
  *   JPEG_HIP_ERR_DC_RANGE  |DC difference| > 2047               (assert, encoder.c:447)
  *   JPEG_HIP_ERR_NO_CODE   symbol absent from the Huffman table  (value_to_vlc == -1, huffman.c:252) */
@@ -145,24 +149,31 @@ int  jpeg_hip_mjpeg_split(const uint8_t *stream, size_t len, size_t *frame_off, 
  *   run       device side: fused prologue (sample -> float, edge replication, RGB -> YCbCr, box-mean
  *             down-sampling, level shift, FDCT, quantise), then entropy coding: [histograms
  *             (write_ecs_dry) -> K.2 tables ->] per-block bit lengths -> prefix sums -> wavefront bit
- *             packing -> 0xFF stuffing (write_ecs).  restart_interval > 0 (in MCUs) is an EXTENSION:
- *             the reference never emits DRI/RSTn.
+ *             packing -> 0xFF stuffing (write_ecs).  Restart markers are an EXTENSION
+ *             (jpeg_hip_encoder_set_restart_interval): the reference never emits DRI/RSTn.
  *   sync      waits, returns per-frame RET_* codes and total codestream lengths.
  */
 typedef struct jpeg_hip_encoder jpeg_hip_encoder;
 
-/* mirrors the reference's command line parameters (struct params, encoder.c:68-88) */
+/* the reference's command line parameters: same members, same layout as `struct params` (encoder.c:68-76),
+ * so that a `struct params *` of the reference's own main() can be passed straight through */
 typedef struct jpeg_hip_params {
 	uint8_t H, V;       /* luma sampling factors, 1 or 2 (-h, -v) */
 	int q;              /* quality 1..100 (-q) */
 	int optimize;       /* optimised Huffman tables (-o) */
-	int restart_interval; /* EXTENSION: MCUs per restart interval, 0 = none */
 } jpeg_hip_params;
 
 int  jpeg_hip_encoder_create(jpeg_hip_encoder **enc, int device);
 void jpeg_hip_encoder_destroy(jpeg_hip_encoder *enc);
 int  jpeg_hip_encoder_configure(jpeg_hip_encoder *enc, int nframes, int X, int Y, int Nf, int P,
                                 const jpeg_hip_params *params);
+/* EXTENSION (the reference writes no DRI / RSTn): MCUs per restart interval, 0..65535,
+ * 0 = none (default).  Read by the next configure(). */
+void jpeg_hip_encoder_set_restart_interval(jpeg_hip_encoder *enc, int mcus);
+/* set_qtable() with the Annex K.1 tables and quality_to_sf() (encoder.c:14-65): Q receives the luminance
+ * (chroma == 0) or chrominance table scaled to quality q, raster order, as struct qtable holds it
+ * (common.h:52-57).  Host only. */
+void jpeg_hip_set_qtable(uint16_t Q[64], int chroma, int q);
 int  jpeg_hip_encoder_info(const jpeg_hip_encoder *enc, jpeg_hip_frame_info *info);
 /* d_samples: nframes PPM/PGM bodies (u8, or big-endian u16 when P > 8), frame_stride bytes apart */
 int  jpeg_hip_encoder_run(jpeg_hip_encoder *enc, const void *d_samples, size_t frame_stride, void *stream);
@@ -235,6 +246,14 @@ int jpeg_hip_encode_pixels(int device, const jpeg_hip_frame_desc *frame, const u
 int jpeg_hip_write_scan(int device, const jpeg_hip_frame_desc *frame, const jpeg_hip_scan_desc *scan,
                         jpeg_hip_htable dc[4], jpeg_hip_htable ac[4], int optimize,
                         const int32_t *const coef[JPEG_HIP_MAX_COMP], uint8_t *out, size_t cap, size_t *n);
+
+/* write_ecs_dry(context, scan), encoder.c:525-558: the statistics of write_block_dry() (coeffs.c:312-363) over
+ * the frame's one interleaved scan and adapt_huffman_table() (huffman.c:508-537) for the tables in use (DC and
+ * AC of id 0, and of id 1 when the frame has three components), RETURNED in dc[] / ac[]: what the reference
+ * leaves in context->htable[][] for produce_DHT().  Follow with jpeg_hip_write_scan(optimize = 0). */
+int jpeg_hip_adapt_tables(int device, const jpeg_hip_frame_desc *frame, const jpeg_hip_scan_desc *scan,
+                          jpeg_hip_htable dc[4], jpeg_hip_htable ac[4],
+                          const int32_t *const coef[JPEG_HIP_MAX_COMP]);
 
 /* ---- single-image drop-ins for the reference's top-level entry points ------------------------
  * Same argument meaning and error behaviour as the functions they replace; the pixel and entropy

@@ -37,6 +37,7 @@ EXPORTS = [
     "jpeg_hip_encoder_set_timing", "jpeg_hip_encoder_get_timing",
     "jpeg_hip_process_jpeg_stream", "jpeg_hip_process_jpeg_file", "jpeg_hip_process_stream",
     "jpeg_hip_read_scan", "jpeg_hip_decode_pixels", "jpeg_hip_encode_pixels", "jpeg_hip_write_scan",
+    "jpeg_hip_adapt_tables", "jpeg_hip_set_qtable", "jpeg_hip_encoder_set_restart_interval",
 ]
 
 
@@ -53,9 +54,8 @@ class FrameInfo(C.Structure):
 
 
 class Params(C.Structure):
-    """struct params of the reference (encoder.c:68-76) + the restart-interval extension."""
-    _fields_ = [("H", C.c_uint8), ("V", C.c_uint8), ("q", C.c_int), ("optimize", C.c_int),
-                ("restart_interval", C.c_int)]
+    """struct params of the reference (encoder.c:68-76), same layout."""
+    _fields_ = [("H", C.c_uint8), ("V", C.c_uint8), ("q", C.c_int), ("optimize", C.c_int)]
 
 
 class FrameDesc(C.Structure):
@@ -141,6 +141,11 @@ def lib():
         L.jpeg_hip_decode_pixels.argtypes = [C.c_int, fdp, vp, cpp, vp]
         L.jpeg_hip_encode_pixels.argtypes = [C.c_int, fdp, vp, vp, cpp]
         L.jpeg_hip_write_scan.argtypes = [C.c_int, fdp, sdp, htp, htp, C.c_int, cpp, vp, sz, C.POINTER(sz)]
+        L.jpeg_hip_adapt_tables.argtypes = [C.c_int, fdp, sdp, htp, htp, cpp]
+        L.jpeg_hip_set_qtable.argtypes = [vp, C.c_int, C.c_int]
+        L.jpeg_hip_set_qtable.restype = None
+        L.jpeg_hip_encoder_set_restart_interval.argtypes = [vp, C.c_int]
+        L.jpeg_hip_encoder_set_restart_interval.restype = None
         _lib = L
     return _lib
 
@@ -307,7 +312,8 @@ class Encoder:
             pass
 
     def configure(self, nframes, X, Y, Nf, P=8, H=2, V=1, q=75, optimize=1, restart_interval=0):
-        prm = Params(H, V, q, optimize, restart_interval)
+        prm = Params(H, V, q, optimize)
+        self.L.jpeg_hip_encoder_set_restart_interval(self.h, int(restart_interval))
         err = self.L.jpeg_hip_encoder_configure(self.h, nframes, X, Y, Nf, P, C.byref(prm))
         if err:
             raise JpegError(err, "jpeg_hip_encoder_configure")

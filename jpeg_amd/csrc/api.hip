@@ -987,6 +987,7 @@ struct jpeg_hip_encoder {
 	int nframes = 0;
 	JhGeom g;
 	jpeg_hip_params prm;
+	int restart_interval = 0;         // EXTENSION, set by jpeg_hip_encoder_set_restart_interval(); read by configure()
 	uint16_t Q[4][64];
 	JhHuffSpec ht[2][4];
 	std::vector<std::vector<uint8_t>> headers;   // per frame
@@ -1059,7 +1060,7 @@ static int upload_codes_and_headers(jpeg_hip_encoder *e, int f0, int f1, hipStre
 				}
 			}
 		}
-		jh_produce_headers(e->g, e->Q, ht, e->prm.restart_interval, &e->headers[f]);
+		jh_produce_headers(e->g, e->Q, ht, e->restart_interval, &e->headers[f]);
 		e->hdr_len[f] = (uint32_t)e->headers[f].size();
 		if (e->hdr_len[f] > 2048) {
 			return RET_FAILURE_LOGIC_ERROR;
@@ -1092,7 +1093,7 @@ static int encoder_configure(jpeg_hip_encoder *enc, int nframes, int X, int Y, i
 	if (Nf == 3 && (params->H < 1 || params->H > 2 || params->V < 1 || params->V > 2)) {
 		return RET_FAILURE_FILE_UNSUPPORTED;               // assert in the reference (encoder.c:123-124)
 	}
-	if (params->restart_interval < 0 || params->restart_interval > 65535) {
+	if (enc->restart_interval < 0 || enc->restart_interval > 65535) {
 		return RET_FAILURE_FILE_UNSUPPORTED;               // DRI holds 16 bits (extension: the reference writes none)
 	}
 	enc->prm = *params;
@@ -1139,7 +1140,7 @@ static int encoder_configure(jpeg_hip_encoder *enc, int nframes, int X, int Y, i
 	w.us_stride = align_up(raw + (size_t)g.nblk * 4 + 65536, 4096);
 	w.nchunk = (int)(w.us_stride / 4096);
 	w.out_stride = align_up(4096 + w.us_stride + w.us_stride / 8, 4096);
-	w.restart_interval = params->restart_interval;
+	w.restart_interval = enc->restart_interval;
 	w.nivl = w.restart_interval > 0 ? (g.nmcu + w.restart_interval - 1) / w.restart_interval : 0;
 
 	// Everything below is sized by (frames, geometry, restart interval): a configure() that changes only the
@@ -1172,7 +1173,7 @@ static int encoder_configure(jpeg_hip_encoder *enc, int nframes, int X, int Y, i
 	{
 		// the header bytes in front of the DHT segments and behind them do not depend on the tables
 		std::vector<uint8_t> full;
-		jh_produce_headers(g, enc->Q, enc->ht, params->restart_interval, &full);
+		jh_produce_headers(g, enc->Q, enc->ht, enc->restart_interval, &full);
 		size_t pos = 2, pre = 0, suf = 0;
 		while (pos + 4 <= full.size()) {
 			const unsigned m = full[pos + 1];
@@ -1642,20 +1643,15 @@ extern "C" int jpeg_hip_encode_pixels(int device, const jpeg_hip_frame_desc *fra
 	return err;
 }
 
-extern "C" int jpeg_hip_write_scan(int device, const jpeg_hip_frame_desc *frame, const jpeg_hip_scan_desc *scan,
-                                   jpeg_hip_htable dc[4], jpeg_hip_htable ac[4], int optimize,
-                                   const int32_t *const coef[JPEG_HIP_MAX_COMP], uint8_t *out, size_t cap, size_t *n)
+// what jpeg_hip_write_scan() and jpeg_hip_adapt_tables() share: an encoder object for one frame of the caller's
+// description with the caller's coefficients uploaded (scan order, zig-zag, int16)
+static int scan_encoder(int device, const jpeg_hip_frame_desc *frame, const jpeg_hip_scan_desc *scan,
+                        const jpeg_hip_htable dc[4], const jpeg_hip_htable ac[4], int optimize,
+                        const int32_t *const coef[JPEG_HIP_MAX_COMP], jpeg_hip_encoder **out_enc)
 {
-	int err = require_device(device);
-	if (err) {
-		return err;
-	}
-	if (!frame || !scan || !dc || !ac || !coef || !n || (!out && cap)) {
-		return RET_FAILURE_LOGIC_ERROR;
-	}
-	*n = 0;
+	*out_enc = nullptr;
 	jpeg_hip_params prm;
-	err = encoder_frame_params(frame, &prm);
+	int err = encoder_frame_params(frame, &prm);
 	if (err) {
 		return err;
 	}
@@ -1670,7 +1666,6 @@ extern "C" int jpeg_hip_write_scan(int device, const jpeg_hip_frame_desc *frame,
 		}
 	}
 	prm.optimize = optimize != 0;
-	prm.restart_interval = scan->restart_interval;
 	JhHuffSpec ht[2][4];
 	for (int th = 0; th < 4; ++th) {
 		const int src = frame->Nf > 1 ? (th & 1) : 0;      // one component: table 0 only
@@ -1688,10 +1683,10 @@ extern "C" int jpeg_hip_write_scan(int device, const jpeg_hip_frame_desc *frame,
 	if (err) {
 		return err;
 	}
+	enc->restart_interval = scan->restart_interval;
 	err = encoder_configure(enc, 1, frame->X, frame->Y, frame->Nf, frame->P, &prm, Q, optimize ? nullptr : ht);
 	if (!err) {
 		const JhGeom &g = enc->g;
-		const JhEncodeWork &w = enc->work;
 		const size_t ncoef = (size_t)g.nblk * 64;
 		std::vector<int16_t> fc(ncoef, 0);
 		bool fits = true;
@@ -1703,18 +1698,61 @@ extern "C" int jpeg_hip_write_scan(int device, const jpeg_hip_frame_desc *frame,
 		} else if (hipMemcpy(enc->d_coefs, fc.data(), ncoef * sizeof(int16_t), hipMemcpyHostToDevice) != hipSuccess ||
 		           hipMemsetAsync(enc->d_state, 0, sizeof(JhEncState), nullptr) != hipSuccess) {
 			err = RET_FAILURE_LOGIC_ERROR;
-		} else if ((optimize && (jh_launch_enc_histogram(w, g, nullptr, nullptr) || jh_launch_enc_adapt(w, g, nullptr, nullptr))) ||
-		           jh_launch_enc_entropy(w, g, nullptr, nullptr)) {
-			err = RET_FAILURE_LOGIC_ERROR;
 		}
+	}
+	if (err) {
+		jpeg_hip_encoder_destroy(enc);
+		return err;
+	}
+	*out_enc = enc;
+	return RET_SUCCESS;
+}
+
+// the tables the device derived (k_enc_adapt), for the caller's DHT segments
+static int fetch_adapted_tables(jpeg_hip_encoder *enc, int Nf, jpeg_hip_htable dc[4], jpeg_hip_htable ac[4])
+{
+	JhDevSpec specs[4];
+	if (hipMemcpy(specs, enc->d_specs, sizeof specs, hipMemcpyDeviceToHost) != hipSuccess) {
+		return RET_FAILURE_LOGIC_ERROR;
+	}
+	for (int th = 0; th < (Nf > 1 ? 2 : 1); ++th) {
+		memcpy(dc[th].L, specs[0 * 2 + th].L, 16);
+		memcpy(dc[th].V, specs[0 * 2 + th].V, 256);
+		memcpy(ac[th].L, specs[1 * 2 + th].L, 16);
+		memcpy(ac[th].V, specs[1 * 2 + th].V, 256);
+	}
+	return RET_SUCCESS;
+}
+
+extern "C" int jpeg_hip_write_scan(int device, const jpeg_hip_frame_desc *frame, const jpeg_hip_scan_desc *scan,
+                                   jpeg_hip_htable dc[4], jpeg_hip_htable ac[4], int optimize,
+                                   const int32_t *const coef[JPEG_HIP_MAX_COMP], uint8_t *out, size_t cap, size_t *n)
+{
+	int err = require_device(device);
+	if (err) {
+		return err;
+	}
+	if (!frame || !scan || !dc || !ac || !coef || !n || (!out && cap)) {
+		return RET_FAILURE_LOGIC_ERROR;
+	}
+	*n = 0;
+	jpeg_hip_encoder *enc = nullptr;
+	err = scan_encoder(device, frame, scan, dc, ac, optimize, coef, &enc);
+	if (err) {
+		return err;
+	}
+	const JhGeom &g = enc->g;
+	const JhEncodeWork &w = enc->work;
+	if ((optimize && (jh_launch_enc_histogram(w, g, nullptr, nullptr) || jh_launch_enc_adapt(w, g, nullptr, nullptr))) ||
+	    jh_launch_enc_entropy(w, g, nullptr, nullptr)) {
+		err = RET_FAILURE_LOGIC_ERROR;
 	}
 	if (!err) {
 		enc->last_stream = nullptr;
 		enc->ran = true;
 		int status = RET_SUCCESS;
 		size_t total = 0;
-		jpeg_hip_encoder_sync(enc, &status, &total);
-		err = status;
+		err = jpeg_hip_encoder_sync(enc, &status, &total);
 		if (!err) {
 			const size_t ecs = enc->state[0].ecs_bytes;
 			*n = ecs;
@@ -1725,22 +1763,50 @@ extern "C" int jpeg_hip_write_scan(int device, const jpeg_hip_frame_desc *frame,
 			}
 		}
 		if (!err && optimize) {
-			// the tables the device derived (k_enc_adapt), for the caller's DHT segments
-			JhDevSpec specs[4];
-			if (hipMemcpy(specs, enc->d_specs, sizeof specs, hipMemcpyDeviceToHost) != hipSuccess) {
-				err = RET_FAILURE_LOGIC_ERROR;
-			} else {
-				for (int th = 0; th < (frame->Nf > 1 ? 2 : 1); ++th) {
-					memcpy(dc[th].L, specs[0 * 2 + th].L, 16);
-					memcpy(dc[th].V, specs[0 * 2 + th].V, 256);
-					memcpy(ac[th].L, specs[1 * 2 + th].L, 16);
-					memcpy(ac[th].V, specs[1 * 2 + th].V, 256);
-				}
-			}
+			err = fetch_adapted_tables(enc, frame->Nf, dc, ac);
 		}
 	}
 	jpeg_hip_encoder_destroy(enc);
 	return err;
+}
+
+extern "C" int jpeg_hip_adapt_tables(int device, const jpeg_hip_frame_desc *frame, const jpeg_hip_scan_desc *scan,
+                                     jpeg_hip_htable dc[4], jpeg_hip_htable ac[4],
+                                     const int32_t *const coef[JPEG_HIP_MAX_COMP])
+{
+	int err = require_device(device);
+	if (err) {
+		return err;
+	}
+	if (!frame || !scan || !dc || !ac || !coef) {
+		return RET_FAILURE_LOGIC_ERROR;
+	}
+	jpeg_hip_encoder *enc = nullptr;
+	err = scan_encoder(device, frame, scan, dc, ac, 1, coef, &enc);
+	if (err) {
+		return err;
+	}
+	if (jh_launch_enc_histogram(enc->work, enc->g, nullptr, nullptr) || jh_launch_enc_adapt(enc->work, enc->g, nullptr, nullptr) ||
+	    hipStreamSynchronize(nullptr) != hipSuccess) {
+		err = RET_FAILURE_LOGIC_ERROR;
+	}
+	if (!err) {
+		err = fetch_adapted_tables(enc, frame->Nf, dc, ac);
+	}
+	jpeg_hip_encoder_destroy(enc);
+	return err;
+}
+
+extern "C" void jpeg_hip_set_qtable(uint16_t Q[64], int chroma, int q)
+{
+	jh_set_qtable(Q, chroma != 0, q);
+}
+
+extern "C" void jpeg_hip_encoder_set_restart_interval(jpeg_hip_encoder *enc, int mcus)
+{
+	if (enc) {
+		enc->restart_interval = mcus;
+	}
 }
 
 

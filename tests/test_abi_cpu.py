@@ -39,11 +39,36 @@ def test_every_entry_point_cites_the_reference(built_lib):
 def test_struct_layouts_match_header(built_lib):
     # jpeg_hip_frame_info: 4 + 6*4 + 6 + 2*4 + 4 ints
     assert C.sizeof(built_lib.FrameInfo) == 4 * (4 + 24 + 6 + 8 + 4)
-    assert C.sizeof(built_lib.Params) == 16
+    assert C.sizeof(built_lib.Params) == 12          # == sizeof(struct params), encoder.c:68-76
     # stage level: jpeg_hip_frame_desc 4 + 3*4 ints, jpeg_hip_htable 16 + 256 bytes, jpeg_hip_scan_desc 1 + 3*4 + 1 ints
     assert C.sizeof(built_lib.FrameDesc) == 4 * 16
     assert C.sizeof(built_lib.HTable) == 272
     assert C.sizeof(built_lib.ScanDesc) == 4 * 14
+
+
+def test_set_qtable_is_the_reference_scaling(built_lib, oracle):
+    """jpeg_hip_set_qtable = set_qtable() + quality_to_sf() + the Annex K.1 tables (encoder.c:14-65); host only."""
+    import numpy as np
+    L = built_lib.lib()
+    for chroma in (0, 1):
+        for q in (-3, 0, 1, 2, 10, 49, 50, 51, 75, 90, 95, 99, 100, 250):
+            Q = np.zeros(64, np.uint16)
+            L.jpeg_hip_set_qtable(Q.ctypes.data, chroma, q)
+            assert np.array_equal(Q, oracle.qtable(chroma, q)), (chroma, q)
+
+
+def test_ref_glue_compiles_against_the_reference_headers(built_lib, tmp_path):
+    """integration/ref_glue.c (the binding of INTEGRATION.md section 2) in strict C99 against the reference's
+    own headers; linking and running need the GPU (tests/test_gpu_ref_glue.py)."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None or not os.path.isdir("/root/reference"):
+        pytest.skip("needs gcc and /root/reference")
+    for which in ("GLUE_DECODER", "GLUE_ENCODER"):
+        subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-D_XOPEN_SOURCE=700",
+                        "-I/root/reference", "-I" + os.path.join(ROOT, "include"), "-D" + which, "-c",
+                        os.path.join(ROOT, "integration", "ref_glue.c"), "-o", str(tmp_path / (which + ".o"))],
+                       check=True, timeout=120)
 
 
 def test_fails_loudly_without_gpu(built_lib):

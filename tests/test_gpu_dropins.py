@@ -58,7 +58,7 @@ def test_files_in_files_out(hip, oracle, tmp_path, case):
     # encoder.c main(): process_stream(i_stream, o_stream, &params)
     jpg = tmp_path / "out.jpg"
     fi, fo = libc.fopen(str(pnm).encode(), b"r"), libc.fopen(str(jpg).encode(), b"w")
-    prm = hip.Params(H, V, q, opt, 0)
+    prm = hip.Params(H, V, q, opt)
     assert L.jpeg_hip_process_stream(fi, fo, C.byref(prm)) == 0
     libc.fclose(fi)
     libc.fclose(fo)
@@ -106,7 +106,7 @@ def test_error_codes_of_the_drop_ins(hip, oracle, tmp_path):
     bad.write_bytes(jpg[:-2])                                                              # no EOI
     assert L.jpeg_hip_process_jpeg_file(str(bad).encode(), str(tmp_path / "o.ppm").encode()) == 0x1000
     # PPM problems: body too short (frame.c:296-299), 16-bit samples beyond P = 12
-    prm = hip.Params(2, 2, 75, 1, 0)
+    prm = hip.Params(2, 2, 75, 1)
     for body, want in ((b"P6\n64 48\n255\n" + bytes(100), 0x1000),
                        (b"P5\n8 8\n65535\n" + bytes(128), 0x1001),
                        (b"P7\n8 8\n255\n" + bytes(64), 0x1001)):
