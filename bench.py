@@ -4,22 +4,31 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--frames F]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself (children of this
+process through torch.distributed.run, before anything here touches a GPU) and exits with their code.
+
 Workload (config.workload): BASELINE.json's metric configuration, 4K (3840x2160) 8-bit 4:2:0 q90,
 default Huffman tables, no restart markers -- the stream the reference encoder itself writes.  One
-STEP = one pass of the hot path over one batch of F synthetic frames per GPU: the batch of
+STEP = one pass of the hot path over one batch of F DISTINCT synthetic frames per GPU: the batch of
 codestreams is DECODED (un-stuffing, speculative Huffman decode, IDCT, colour) and the batch of
 images is ENCODED (colour, FDCT, quantise, Huffman bit-packing, stuffing).  Inputs are resident in
 HBM before the timed region; outputs stay in HBM.  value = pixels that went through decode AND
 encode per second, whole job (all ranks).  Frames shard across ranks with no data-path
 collective (Motion-JPEG semantics) => "scaling": "weak".
 
-Extra keys: decode / encode rates measured separately, the MJPEG (1080p 4:2:2 q85) frame rate,
-"roofline" for the dominant kernel (HIP-event time per launch against algorithmic bytes,
-SURVEY.md section 8d) and "cpu_baseline" (the compiled reference, oracle/_ref, on one host core).
+Extra keys: decode / encode rates measured separately; "workloads": the other BASELINE configurations
+(C2 4K 4:4:4 q90 with one restart interval per MCU row, C3 8K 12-bit gray, C4 8K 4:2:0 optimised
+tables, C5 1080p 4:2:2 Motion JPEG), each with its own algorithmic bytes and dominant kernel;
+"mjpeg_stream": BASELINE's 10 000-frame 1080p stream sharded over the ranks, host-inclusive
+(codestreams in host memory -> samples in HBM), per rank and in total, with the frame count and a
+checksum of checksums gathered over the ranks and compared with the single-process totals;
+"roofline" for the dominant kernel (HIP-event time per launch against algorithmic bytes, SURVEY.md
+section 8d) and "cpu_baseline" (the compiled reference, oracle/_ref, on one host core).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -29,22 +38,32 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+STREAM_FRAMES = 10000          # BASELINE.json configs[4]: Motion JPEG 1080p 4:2:2 q85, 10k frames
 
 
-def make_batch(binding, synth, name, nframes, device, distinct=4):
-    """Synthetic frames -> (device tensor of PPM bodies, list of JPEG codestreams from OUR encoder
-    (bit-exact vs the oracle, tests/test_gpu_parity.py), geometry info)."""
+def make_batch(torch, binding, synth, name, nframes, device, restart_interval=0):
+    """nframes DISTINCT synthetic frames, generated on the device (jpeg_amd.synth.synth_body_torch: the
+    integer-only recipe of SURVEY 8d, bit-identical to the numpy generator the parity tests use)
+    -> (encoder, device tensor of PPM/PGM bodies, JPEG codestreams from OUR encoder (bit-exact vs the
+    oracle, tests/), configuration)."""
     X, Y, nc, P, H, V, q, opt, safe, seed = synth.CONFIGS[name]
-    base = [synth.synth_image(X, Y, nc, P, seed, safe, frame=i) for i in range(min(distinct, nframes))]
-    imgs = [base[i % len(base)] for i in range(nframes)]
+    dev = "cuda:%d" % device
+    samples = torch.stack([synth.synth_body_torch(X, Y, nc, P, seed, safe, frame=i, device=dev) for i in range(nframes)])
     enc = binding.Encoder(device)
-    enc.configure(nframes, X, Y, nc, P, H, V, q, opt)
-    samples = enc.upload(imgs)
+    enc.configure(nframes, X, Y, nc, P, H, V, q, opt, restart_interval)
     enc.run(samples)
     st, ln = enc.sync()
     assert all(s == 0 for s in st), st
     jpgs = [enc.jpeg(f, ln[f]) for f in range(nframes)]
-    return enc, samples, jpgs, imgs, dict(X=X, Y=Y, nc=nc, P=P, H=H, V=V, q=q, opt=opt)
+    return enc, samples, jpgs, dict(X=X, Y=Y, nc=nc, P=P, H=H, V=V, q=q, opt=opt, Ri=restart_interval)
+
+
+def host_image(samples, f, cfg):
+    """frame f of a device batch as the numpy array the CPU codecs take"""
+    raw = samples[f].cpu().numpy().tobytes()
+    a = np.frombuffer(raw, np.uint8 if cfg["P"] <= 8 else np.dtype(">u2"))
+    a = a.reshape(cfg["Y"], cfg["X"], cfg["nc"]).astype(np.uint8 if cfg["P"] <= 8 else np.uint16)
+    return a[:, :, 0] if cfg["nc"] == 1 else a
 
 
 def timed(torch, fn, steps, warmup, dist):
@@ -62,10 +81,14 @@ def timed(torch, fn, steps, warmup, dist):
         dist.barrier()
     t = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([t], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        t = float(tt.item())
+        t = reduce_max(torch, dist, t)
     return t
+
+
+def reduce_max(torch, dist, v):
+    tt = torch.tensor([v], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    return float(tt.item())
 
 
 def kernel_times(obj, run, torch, reps=5):
@@ -97,6 +120,113 @@ def pmc_traffic(kernel, frames):
     return int(k["hbm_bytes"] * frames / d["frames_per_launch"])
 
 
+def measure_workload(torch, binding, synth, name, nframes, device, steps, restart_interval=0):
+    """decode and encode rates of one BASELINE configuration on one GPU, device-resident, with the per-kernel
+    HIP-event times and the algorithmic-byte roofline of its dominant kernel."""
+    enc, samples, jpgs, cfg = make_batch(torch, binding, synth, name, nframes, device, restart_interval)
+    dec = binding.Decoder(device)
+    dec.prepare(jpgs)
+    out = dec.alloc_output()
+    pix = cfg["X"] * cfg["Y"]
+    t_d = timed(torch, lambda: dec.run(out), steps, 2, None)
+    t_e = timed(torch, lambda: enc.run(samples), steps, 2, None)
+    assert all(s == 0 for s in dec.sync()) and all(s == 0 for s in enc.sync()[0])
+    stats = dec.stats(0)
+    allk = kernel_times(dec, lambda: dec.run(out), torch, reps=3)
+    allk.update(kernel_times(enc, lambda: enc.run(samples), torch, reps=3))
+    dom = max(allk, key=allk.get)
+    sbytes = 1 if cfg["P"] <= 8 else 2
+    alg = nframes * pix * cfg["nc"] * sbytes + sum(len(j) for j in jpgs)
+    res = {
+        "frames_per_step": nframes, "distinct_frames": nframes,
+        "decode_mpix_s": round(nframes * pix * steps / t_d / 1e6, 1),
+        "encode_mpix_s": round(nframes * pix * steps / t_e / 1e6, 1),
+        "jpeg_bytes_per_frame": sum(len(j) for j in jpgs) // nframes,
+        "alg_bytes_per_step": alg,
+        "pipeline_hbm_frac": {"decode": round(alg / (t_d / steps) / 1e9 / HBM_PEAK_GBS, 5),
+                              "encode": round(alg / (t_e / steps) / 1e9 / HBM_PEAK_GBS, 5)},
+        "dominant_kernel": dom, "dominant_kernel_ms": round(allk[dom], 4),
+        "dominant_kernel_frac": round(alg / (allk[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+        "kernel_ms": {k: round(v, 4) for k, v in sorted(allk.items(), key=lambda kv: -kv[1])[:6]},
+        "huffman_serial_fallback": bool(stats[0]), "restart_segments_per_frame": stats[3],
+    }
+    enc.close()
+    dec.close()
+    return res
+
+
+def frame_sums(torch, out):
+    """per-frame checksum of a decoded batch, computed on the device: the frame's bytes summed as 64-bit words
+    (wrapping), 61 bits kept"""
+    n = out.shape[1]
+    if n % 8 == 0 and out.is_contiguous():
+        s = out.view(torch.int64).sum(dim=1)
+    else:
+        s = out.sum(dim=1, dtype=torch.int64)
+    return s & ((1 << 61) - 1)
+
+
+def mjpeg_stream(torch, binding, synth, mjpeg, dev, rank, world, dist, batch, distinct=32):
+    """BASELINE configs[4]: a 10 000-frame 1080p 4:2:2 q85 Motion JPEG stream sharded over the ranks with
+    mjpeg.shard (contiguous chunks, no data-path collective).  Host-inclusive: codestreams in pageable host
+    memory -> decoded samples in HBM (header parsing, Huffman table set-up, PCIe upload, kernels)."""
+    enc, samples, jpgs, cfg = make_batch(torch, binding, synth, "c5_1080p_422_q85", distinct, dev)
+    enc.close()
+    del samples
+    stream = [jpgs[i % distinct] for i in range(STREAM_FRAMES)]
+    lo, hi = mjpeg.shard(STREAM_FRAMES, rank, world)
+    mine = stream[lo:hi]
+
+    # expected totals of the WHOLE stream as one process would see them: the stream repeats `distinct` frames
+    d = binding.Decoder(dev)
+    d.prepare(jpgs)
+    o = d.run()
+    assert all(s == 0 for s in d.sync())
+    sums = [int(v) for v in frame_sums(torch, o).tolist()]
+    d.close()
+    del o
+    expect_cs = mjpeg.combine_checksums(sums[i % distinct] for i in range(STREAM_FRAMES))
+    expect_bytes = sum(len(stream[i]) for i in range(STREAM_FRAMES))
+
+    best = None
+    for attempt in range(2):                               # first pass creates the pinned buffers and workspaces
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        t0 = time.perf_counter()
+        n = 0
+        acc = []
+        for o, st in mjpeg.decode_stream(mine, batch=batch, device=dev):
+            assert all(s == 0 for s in st)
+            acc.append(frame_sums(torch, o))
+            n += o.shape[0]
+        torch.cuda.synchronize()
+        t_rank = time.perf_counter() - t0
+        if dist is not None:
+            dist.barrier()
+        t_all = time.perf_counter() - t0
+        if dist is not None:
+            t_all = reduce_max(torch, dist, t_all)
+        best = (t_rank, t_all)
+    got = [int(v) for v in torch.cat(acc).tolist()]
+    local = {"frames": n, "bytes": sum(len(j) for j in mine), "checksum": mjpeg.combine_checksums(got)}
+    tot = mjpeg.gather_stats(local, dist)
+    ok = tot["frames"] == STREAM_FRAMES and tot["bytes"] == expect_bytes and tot["checksum"] == expect_cs
+    rates = [n / best[0]]
+    if dist is not None:
+        tt = torch.tensor([n / best[0]], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        allv = [torch.zeros_like(tt) for _ in range(world)]
+        dist.all_gather(allv, tt)
+        rates = [float(v.item()) for v in allv]
+    return {
+        "frames": tot["frames"], "distinct_frames": distinct, "batch": batch, "bytes_per_frame": expect_bytes // STREAM_FRAMES,
+        "host_inclusive_decode_frames_per_s": round(STREAM_FRAMES / best[1], 1),
+        "per_rank_frames_per_s": [round(r, 1) for r in rates],
+        "gathered": {"frames": tot["frames"], "bytes": tot["bytes"], "checksum": tot["checksum"]},
+        "matches_single_process_totals": ok,
+    }
+
+
 def cpu_baseline(imgs, jpgs, cfg, budget_s=20.0):
     """The compiled reference (oracle/_ref: unmodified sources) on ONE host core: decode + encode of
     whole 4K frames, in process, files in memory/tmpfs.  Bounded sample (~10-30 s)."""
@@ -106,7 +236,9 @@ def cpu_baseline(imgs, jpgs, cfg, budget_s=20.0):
         kind = "reference"
         enc = lambda im: ref.encode(im, P=cfg["P"], H=cfg["H"], V=cfg["V"], q=cfg["q"], optimize=cfg["opt"])
         dec = lambda j: ref.decode(j)
-    except Exception:
+    except Exception as e:
+        sys.stderr.write("bench.py: WARNING: oracle/_ref (the compiled reference) is not usable here (%r); the CPU "
+                         "baseline below times OUR scalar restatement instead -> cpu_baseline.kind = \"port\"\n" % (e,))
         from oracle.pyoracle import Oracle
         orc = Oracle()
         kind = "port"
@@ -162,7 +294,6 @@ def cpu_baseline_mjpeg(seconds=8.0):
     """frames are independent, so the CPU side of the Motion-JPEG comparison is N copies of the
     single-threaded reference on N host cores (N = this box's CPU share, at most 16).  Children of this
     process, each a plain python without GPU."""
-    import subprocess
     cores = max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)))
     procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(seconds)],
                               stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, cwd=ROOT) for _ in range(cores)]
@@ -176,6 +307,18 @@ def cpu_baseline_mjpeg(seconds=8.0):
             "sample": "%d processes x %.0f s of decode + encode of 1080p 4:2:2 q85 frames, compiled reference" % (cores, seconds)}
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` on its own: start the N ranks as children (torch.distributed.run, one process
+    per GPU) BEFORE this process touches a GPU, pass their output through, exit with their code."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, cwd=ROOT)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cpu-worker", type=float, default=0.0, help=argparse.SUPPRESS)
@@ -183,9 +326,10 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=128, help="4K frames per GPU per step")
-    ap.add_argument("--mjpeg-frames", type=int, default=256, help="1080p frames per GPU per step (extra line)")
+    ap.add_argument("--mjpeg-frames", type=int, default=256, help="1080p frames per GPU per batch (Motion JPEG lines)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-mjpeg", action="store_true")
+    ap.add_argument("--no-workloads", action="store_true", help="skip the C2..C5 lines")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; gloo rehearses the multi-rank path "
                                                       "with several ranks on ONE GPU (RCCL refuses that)")
     ap.add_argument("--one-stream", action="store_true",
@@ -195,11 +339,15 @@ def main():
     if args.cpu_worker > 0:
         cpu_worker(args.cpu_worker)
         return
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
 
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d: the launcher decides, n_gpus = %d\n" % (args.gpus, world, world))
     dist = None
     if args.backend != "nccl":
         local = local % torch.cuda.device_count()          # rehearsal: ranks share the GPUs there are
@@ -214,11 +362,11 @@ def main():
         dist = dist_mod
     else:
         torch.cuda.set_device(local)
-    from jpeg_amd import binding, synth
+    from jpeg_amd import binding, synth, mjpeg
 
     dev = local
     F = args.frames
-    enc, samples, jpgs, imgs, cfg = make_batch(binding, synth, "metric_4k_420_q90", F, dev)
+    enc, samples, jpgs, cfg = make_batch(torch, binding, synth, "metric_4k_420_q90", F, dev)
     dec = binding.Decoder(dev)
     dec.prepare(jpgs)
     out = dec.alloc_output()
@@ -239,8 +387,9 @@ def main():
     dec.run(out)
     st = dec.sync()
     assert all(s == 0 for s in st), st
-    got = dec.to_arrays(out)[0]
-    assert np.abs(got.astype(int) - imgs[0].astype(int)).max() < 64
+    for f in (0, F - 1):
+        diff = (out[f].to(torch.int16) - samples[f].to(torch.int16)).abs().max().item()
+        assert diff < 64, diff
 
     t = timed(torch, step, args.steps, args.warmup, dist)
     assert all(s == 0 for s in dec.sync()) and all(s == 0 for s in enc.sync()[0])
@@ -257,7 +406,8 @@ def main():
         "dtype_detail": "pixel kernels: binary32 DCT / quantisation and binary64 colour maths, bit-exact with the reference; "
                         "entropy kernels: u8 / int16 / u32 integer work",
         "config": {"workload": "metric_4k_420_q90: 3840x2160 8-bit 4:2:0 q90, default Huffman tables, no restart markers",
-                   "frames_per_gpu_per_step": F, "parallelism": "frames sharded over %d GPU(s), no collectives" % world},
+                   "frames_per_gpu_per_step": F, "distinct_frames": F,
+                   "parallelism": "frames sharded over %d GPU(s), no collectives" % world},
         "decode_mpix_s": round(world * F * pix * args.steps / t_d / 1e6, 1),
         "encode_mpix_s": round(world * F * pix * args.steps / t_e / 1e6, 1),
     }
@@ -278,44 +428,31 @@ def main():
         res["kernel_ms"] = {k: round(v, 4) for k, v in sorted(allk.items(), key=lambda kv: -kv[1])}
         res["pipeline_hbm_frac"] = {"decode": round(alg_bytes / (t_d / args.steps) / 1e9 / HBM_PEAK_GBS, 5),
                                     "encode": round(alg_bytes / (t_e / args.steps) / 1e9 / HBM_PEAK_GBS, 5)}
+    cpu_imgs = [host_image(samples, f, cfg) for f in range(4)] if rank == 0 and world == 1 and not args.no_cpu else None
+    cpu_jpgs = jpgs[:4]
+    enc.close()
+    dec.close()
+    del out, samples
+
+    if rank == 0 and world == 1 and not args.no_workloads:
+        # ---- the other BASELINE configurations, one GPU, device-resident -----------------------
+        res["workloads"] = {}
+        for name, nf, ri in (("c2_4k_444_q90", 32, 480), ("c3_8k_gray12_q95", 16, 0), ("c4_8k_420_q95", 16, 0),
+                             ("c5_1080p_422_q85", args.mjpeg_frames, 0)):
+            w = measure_workload(torch, binding, synth, name, nf, dev, args.steps, ri)
+            if name.startswith("c5"):
+                w["decode_frames_per_s"] = round(w["decode_mpix_s"] * 1e6 / (1920 * 1080), 1)
+                w["encode_frames_per_s"] = round(w["encode_mpix_s"] * 1e6 / (1920 * 1080), 1)
+            res["workloads"][name + ("_ri%d" % ri if ri else "")] = w
 
     if not args.no_mjpeg:
-        # ---- Motion JPEG: 1080p 4:2:2 q85 frames, sharded over ranks ---------------------------
-        Fm = args.mjpeg_frames
-        enc.close()
-        dec.close()
-        del out, samples
-        enc2, samples2, jpgs2, imgs2, cfg2 = make_batch(binding, synth, "c5_1080p_422_q85", Fm, dev, distinct=4)
-        dec2 = binding.Decoder(dev)
-        dec2.prepare(jpgs2)
-        out2 = dec2.alloc_output()
-        td = timed(torch, lambda: dec2.run(out2), args.steps, 2, dist)
-        te = timed(torch, lambda: enc2.run(samples2), args.steps, 2, dist)
-        assert all(s == 0 for s in dec2.sync()) and all(s == 0 for s in enc2.sync()[0])
-        res["mjpeg_1080p_422_q85"] = {"decode_frames_per_s": round(world * Fm * args.steps / td, 1),
-                                      "encode_frames_per_s": round(world * Fm * args.steps / te, 1),
-                                      "frames_per_gpu_per_step": Fm, "bytes_per_frame": len(jpgs2[0])}
-
-        if rank == 0 and world == 1:
-            # host-inclusive (NOT `value`): codestreams in pageable host memory -> samples in HBM, with the
-            # double-buffered stream helper; PCIe H2D, header parsing and Huffman table set-up included
-            from jpeg_amd import mjpeg
-            enc2.close()
-            dec2.close()
-            del out2, samples2
-            nb = 40                                        # 10 240 frames: the 10 000-frame stream of BASELINE.json
-            for _ in range(2):
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                n = 0
-                for o, st in mjpeg.decode_stream(jpgs2 * nb, batch=Fm):
-                    n += o.shape[0]
-                torch.cuda.synchronize()
-                th = time.perf_counter() - t0
-            res["mjpeg_1080p_422_q85"]["host_inclusive_decode_frames_per_s"] = round(n / th, 1)
+        ms = mjpeg_stream(torch, binding, synth, mjpeg, dev, rank, world, dist, args.mjpeg_frames)
+        assert ms["matches_single_process_totals"], ms
+        res["mjpeg_stream_1080p_422_q85"] = ms
+        mjpeg.release_stream_decoders()
 
     if rank == 0 and world == 1 and not args.no_cpu:
-        res["cpu_baseline"] = cpu_baseline(imgs, jpgs, cfg)
+        res["cpu_baseline"] = cpu_baseline(cpu_imgs, cpu_jpgs, cfg)
         if not args.no_mjpeg:
             try:
                 res["cpu_baseline"]["mjpeg_1080p_422_q85"] = cpu_baseline_mjpeg()

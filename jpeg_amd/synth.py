@@ -52,7 +52,9 @@ def synth_image(X, Y, ncomp=3, P=8, seed=0, range_safe=False, frame=0):
     for k in range(ncomp):
         a = 3 * (k + 1) if not range_safe else 3
         b = 5 * (k + 2) if not range_safe else 5
-        ph1 = (a * xx * 65536) // X + (2 * yy * 65536) // Y + 4096 * frame
+        # frames differ by a phase shift and by their noise; the range-safe variant keeps the phase (the first
+        # block's DC and every DC difference must stay inside +-2047) and differs by noise only
+        ph1 = (a * xx * 65536) // X + (2 * yy * 65536) // Y + (0 if range_safe else 4096 * frame)
         ph2 = (7 * xx * 65536) // X - (b * yy * 65536) // Y
         if not range_safe:
             ph2 = ph2 + 16384                                    # +1/4 turn: cosine
@@ -77,3 +79,53 @@ def config_image(name, scale=1, frame=0):
     """Image of a named BASELINE config; scale > 1 shrinks both dimensions (parity-test sizes)."""
     X, Y, nc, P, H, V, q, opt, safe, seed = CONFIGS[name]
     return synth_image(X // scale, Y // scale, nc, P, seed, safe, frame), dict(P=P, H=H, V=V, q=q, optimize=opt)
+
+
+def synth_body_torch(X, Y, ncomp=3, P=8, seed=0, range_safe=False, frame=0, device="cuda"):
+    """The same image as synth_image(), computed with torch int64 on `device`, as the PPM/PGM BODY the
+    encoder reads: uint8 tensor of Y*X*ncomp bytes (P <= 8) or Y*X*ncomp big-endian 16-bit samples.
+    Integer-only like the numpy version, so the two are bit-identical (tests/test_gpu_parity.py); bench.py
+    uses it to make a batch of distinct frames without minutes of host arithmetic."""
+    import torch
+    maxval = (1 << P) - 1
+    yy = torch.arange(Y, dtype=torch.int64, device=device).view(Y, 1)
+    xx = torch.arange(X, dtype=torch.int64, device=device).view(1, X)
+
+    def isin(ph):
+        ph = ph & 0xFFFF
+        half = ph & 0x7FFF
+        mag = (half * (32768 - half)) >> 13
+        return torch.where((ph & 0x8000) != 0, -mag, mag)
+
+    def hash32(x):
+        m = 0xFFFFFFFF
+        x = x & m
+        x = x ^ (x >> 16)
+        x = (x * 0x7FEB352D) & m
+        x = x ^ (x >> 15)
+        x = (x * 0x846CA68B) & m                               # wraps in int64: the low 32 bits are what counts
+        x = x ^ (x >> 16)
+        return x
+
+    fdiv = lambda a, b: torch.div(a, b, rounding_mode="floor")
+    planes = []
+    for k in range(ncomp):
+        a = 3 * (k + 1) if not range_safe else 3
+        b = 5 * (k + 2) if not range_safe else 5
+        ph1 = fdiv(a * xx * 65536, X) + fdiv(2 * yy * 65536, Y) + (0 if range_safe else 4096 * frame)
+        ph2 = fdiv(7 * xx * 65536, X) - fdiv(b * yy * 65536, Y)
+        if not range_safe:
+            ph2 = ph2 + 16384
+        s1, s2 = isin(ph1), isin(ph2)
+        h = hash32(xx * 0x9E3779B1 + yy * 0x85EBCA77 + (k + 1) * 0xC2B2AE3D + (seed + 1) * 0x27D4EB2F + frame * 0x165667B1)
+        noise = ((h & 0xFF) + ((h >> 8) & 0xFF) + ((h >> 16) & 0xFF) + ((h >> 24) & 0xFF)) - 510
+        if range_safe:
+            v = 32768 * 50 + 20 * s1 + 10 * s2 + fdiv(noise * 32768 * 1, 148)
+        else:
+            v = 32768 * 50 + 25 * s1 + 15 * s2 + fdiv(noise * 32768 * 3, 148)
+        v = fdiv(v * maxval + 50 * 32768, 100 * 32768)
+        planes.append(torch.clamp(v, 0, maxval))
+    img = torch.stack(planes, dim=2)                           # [Y, X, ncomp] int64
+    if P <= 8:
+        return img.to(torch.uint8).reshape(-1)
+    return torch.stack([(img >> 8) & 0xFF, img & 0xFF], dim=3).to(torch.uint8).reshape(-1)

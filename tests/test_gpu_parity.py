@@ -583,3 +583,15 @@ def test_randomised_cases(hip, oracle):
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz.py"), "60", "7"], cwd=root,
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_device_side_image_generator_matches_the_host_one(hip):
+    """bench.py makes its batches of distinct frames on the GPU (jpeg_amd.synth.synth_body_torch); the recipe is
+    integer-only, so the bodies must be the bytes of synth_image() -- the generator every parity test uses."""
+    import torch
+    from jpeg_amd.synth import synth_body_torch
+    from oracle.pyoracle import pnm_body
+    for X, Y, nc, P, seed, safe, fr in [(200, 120, 3, 8, 90, False, 7), (96, 64, 1, 12, 3, True, 2), (64, 40, 3, 12, 9, False, 1)]:
+        want = pnm_body(synth_image(X, Y, nc, P, seed, safe, frame=fr), P)
+        got = synth_body_torch(X, Y, nc, P, seed, safe, frame=fr, device="cuda:0").cpu().numpy().tobytes()
+        assert got == want, (X, Y, nc, P)
