@@ -186,6 +186,30 @@ int  jpeg_hip_encoder_get_coefficients(jpeg_hip_encoder *enc, int frame, int k, 
 void jpeg_hip_encoder_set_timing(jpeg_hip_encoder *enc, int on);
 int  jpeg_hip_encoder_get_timing(jpeg_hip_encoder *enc, const char **names, float *ms, int cap);
 
+/* ---- one frame, no device allocation ---------------------------------------------------------
+ * NO COUNTERPART IN THE REFERENCE.  For callers that cannot allocate device memory: code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc.  jpeg_hip_encoder_run() for ONE frame:
+ * same kernels, same bytes, but every buffer beyond the samples and the codestream (coefficients, bit lengths,
+ * prefix sums, the unstuffed stream, histograms, tables, state) lives in one fixed device array inside the
+ * library (jpeg_hip_encode_noalloc_limit() bytes, 32 MiB, held per GPU until the process ends).  The call
+ * allocates nothing (no hipMalloc / hipFree, no host-to-device copy: the tables travel as kernel arguments),
+ * is asynchronous on `stream`, and refuses frames whose workspace does not fit with RET_FAILURE_OVERFLOW_ERROR
+ * and a message (1920x1088 4:4:4 8-bit fits, 4K does not: use the encoder object).  No restart markers.
+ *   d_samples  the PPM/PGM body (X*Y*Nf samples, u8, or big-endian u16 when P > 8), device memory
+ *   d_jpeg     receives SOI .. EOI; cap bytes, at least 8192
+ *   d_result   two 32-bit words in device memory: [0] the frame's RET / JPEG_HIP_ERR code as
+ *              jpeg_hip_encoder_sync() reports it (RET_FAILURE_OVERFLOW_ERROR: cap or the fixed array was
+ *              too small for this image's entropy-coded data), [1] the codestream length (0 on error)
+ * All calls on one GPU share that GPU's array: calls that overlap in time on one GPU (two streams, two
+ * threads) race -- serialise them. */
+size_t jpeg_hip_encode_noalloc_limit(void);
+/* optional set-up, once per device, OUTSIDE the caller's no-allocation region: the runtime loads the library's
+ * code object on the device here and the fixed array comes into being with it (otherwise that happens inside
+ * the first jpeg_hip_encode_noalloc() call on the device) */
+int jpeg_hip_encode_noalloc_init(int device);
+int jpeg_hip_encode_noalloc(int device, const jpeg_hip_params *params, int X, int Y, int Nf, int P,
+                            const void *d_samples, void *d_jpeg, size_t cap, uint32_t *d_result, void *stream);
+
 /* ---- stage level: the four hot loops, one call each, on what `struct context` holds ------------
  * For a maintainer who keeps the reference's own marker parser and producer (parse_format()
  * decoder.c:472-659, produce_codestream() encoder.c:589-645) and swaps only the loops (SURVEY.md

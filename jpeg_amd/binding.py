@@ -38,6 +38,7 @@ EXPORTS = [
     "jpeg_hip_process_jpeg_stream", "jpeg_hip_process_jpeg_file", "jpeg_hip_process_stream",
     "jpeg_hip_read_scan", "jpeg_hip_decode_pixels", "jpeg_hip_encode_pixels", "jpeg_hip_write_scan",
     "jpeg_hip_adapt_tables", "jpeg_hip_set_qtable", "jpeg_hip_encoder_set_restart_interval",
+    "jpeg_hip_encode_noalloc", "jpeg_hip_encode_noalloc_limit", "jpeg_hip_encode_noalloc_init",
 ]
 
 
@@ -142,6 +143,8 @@ def lib():
         L.jpeg_hip_encode_pixels.argtypes = [C.c_int, fdp, vp, vp, cpp]
         L.jpeg_hip_write_scan.argtypes = [C.c_int, fdp, sdp, htp, htp, C.c_int, cpp, vp, sz, C.POINTER(sz)]
         L.jpeg_hip_adapt_tables.argtypes = [C.c_int, fdp, sdp, htp, htp, cpp]
+        L.jpeg_hip_encode_noalloc.argtypes = [C.c_int, C.POINTER(Params), C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, sz, vp, vp]
+        L.jpeg_hip_encode_noalloc_limit.restype = sz
         L.jpeg_hip_set_qtable.argtypes = [vp, C.c_int, C.c_int]
         L.jpeg_hip_set_qtable.restype = None
         L.jpeg_hip_encoder_set_restart_interval.argtypes = [vp, C.c_int]

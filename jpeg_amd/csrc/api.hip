@@ -15,6 +15,7 @@
 #include <chrono>
 #include <string>
 #include <functional>
+#include <mutex>
 #include "../../include/jpeg_amd.h"
 #include "common.hpp"
 #include "codestream.hpp"
@@ -1074,6 +1075,47 @@ static int upload_codes_and_headers(jpeg_hip_encoder *e, int f0, int f1, hipStre
 	return RET_SUCCESS;
 }
 
+// the header bytes in front of the DHT segments [0, pre) and behind them [suf, size) do not depend on the tables
+static bool split_headers(const std::vector<uint8_t> &full, size_t *pre_out, size_t *suf_out)
+{
+	size_t pos = 2, pre = 0, suf = 0;
+	while (pos + 4 <= full.size()) {
+		const unsigned m = full[pos + 1];
+		if (m == 0xc4 && pre == 0) {
+			pre = pos;
+		}
+		if (pre != 0 && m != 0xc4) {
+			suf = pos;
+			break;
+		}
+		pos += 2 + (((size_t)full[pos + 2] << 8) | full[pos + 3]);
+	}
+	*pre_out = pre;
+	*suf_out = suf;
+	return pre != 0 && suf != 0 && full.size() <= 4096;
+}
+
+// read_image() component set-up (encoder.c:109-146): ids 1..3, luma H x V, chroma 1 x 1
+static int encoder_geometry(int X, int Y, int Nf, int P, const jpeg_hip_params *params, JhGeom *g)
+{
+	if ((Nf != 1 && Nf != 3) || X <= 0 || Y <= 0 || X > 65535 || Y > 65535) {
+		return RET_FAILURE_FILE_UNSUPPORTED;               // encoder.c:147-148
+	}
+	if (Nf == 3 && (params->H < 1 || params->H > 2 || params->V < 1 || params->V > 2)) {
+		return RET_FAILURE_FILE_UNSUPPORTED;               // assert in the reference (encoder.c:123-124)
+	}
+	memset(g, 0, sizeof *g);
+	g->P = P; g->X = X; g->Y = Y; g->Nf = Nf; g->ncomp = Nf;
+	for (int k = 0; k < Nf; ++k) {
+		g->id[k] = k + 1;
+		g->H[k] = (k == 0 && Nf == 3) ? params->H : 1;
+		g->V[k] = (k == 0 && Nf == 3) ? params->V : 1;
+		g->Tq[k] = g->Td[k] = g->Ta[k] = k == 0 ? 0 : 1;
+		g->scan_order[k] = k;
+	}
+	return jh_finish_geometry(g);
+}
+
 // Q / ht: tables of the caller instead of the quality-scaled and the default ones (stage level API)
 static int encoder_configure(jpeg_hip_encoder *enc, int nframes, int X, int Y, int Nf, int P,
                              const jpeg_hip_params *params, const uint16_t (*Q)[64], const JhHuffSpec (*ht)[4])
@@ -1087,28 +1129,12 @@ static int encoder_configure(jpeg_hip_encoder *enc, int nframes, int X, int Y, i
 	}
 	enc->ran = false;
 	enc->nframes = 0;                                      // not configured until everything below has succeeded
-	if ((Nf != 1 && Nf != 3) || X <= 0 || Y <= 0 || X > 65535 || Y > 65535) {
-		return RET_FAILURE_FILE_UNSUPPORTED;               // encoder.c:147-148
-	}
-	if (Nf == 3 && (params->H < 1 || params->H > 2 || params->V < 1 || params->V > 2)) {
-		return RET_FAILURE_FILE_UNSUPPORTED;               // assert in the reference (encoder.c:123-124)
-	}
 	if (enc->restart_interval < 0 || enc->restart_interval > 65535) {
 		return RET_FAILURE_FILE_UNSUPPORTED;               // DRI holds 16 bits (extension: the reference writes none)
 	}
 	enc->prm = *params;
 	JhGeom &g = enc->g;
-	memset(&g, 0, sizeof g);
-	g.P = P; g.X = X; g.Y = Y; g.Nf = Nf; g.ncomp = Nf;
-	// read_image() component set-up (encoder.c:109-146): ids 1..3, luma H x V, chroma 1 x 1
-	for (int k = 0; k < Nf; ++k) {
-		g.id[k] = k + 1;
-		g.H[k] = (k == 0 && Nf == 3) ? params->H : 1;
-		g.V[k] = (k == 0 && Nf == 3) ? params->V : 1;
-		g.Tq[k] = g.Td[k] = g.Ta[k] = k == 0 ? 0 : 1;
-		g.scan_order[k] = k;
-	}
-	int err = jh_finish_geometry(&g);
+	int err = encoder_geometry(X, Y, Nf, P, params, &g);
 	if (err) {
 		return err;
 	}
@@ -1174,19 +1200,8 @@ static int encoder_configure(jpeg_hip_encoder *enc, int nframes, int X, int Y, i
 		// the header bytes in front of the DHT segments and behind them do not depend on the tables
 		std::vector<uint8_t> full;
 		jh_produce_headers(g, enc->Q, enc->ht, enc->restart_interval, &full);
-		size_t pos = 2, pre = 0, suf = 0;
-		while (pos + 4 <= full.size()) {
-			const unsigned m = full[pos + 1];
-			if (m == 0xc4 && pre == 0) {
-				pre = pos;
-			}
-			if (pre != 0 && m != 0xc4) {
-				suf = pos;
-				break;
-			}
-			pos += 2 + (((size_t)full[pos + 2] << 8) | full[pos + 3]);
-		}
-		if (pre == 0 || suf == 0 || full.size() > 4096) {
+		size_t pre = 0, suf = 0;
+		if (!split_headers(full, &pre, &suf)) {
 			return RET_FAILURE_LOGIC_ERROR;
 		}
 		HIPCHK(hipMemcpy(enc->d_hdr_parts, full.data(), pre, hipMemcpyHostToDevice));
@@ -1360,6 +1375,257 @@ extern "C" int jpeg_hip_encoder_get_timing(jpeg_hip_encoder *enc, const char **n
 {
 	hipSetDevice(enc->device);
 	return enc->timer.collect(names, ms, cap);
+}
+
+// ======================================================================================= no-allocation entry point
+
+// jpeg_hip_encode_noalloc(): jpeg_hip_encoder_run() for ONE frame without any device allocation.  No
+// counterpart in the reference; for callers that cannot call hipMalloc (HIP graph capture, tight serving
+// loops, harnesses that forbid it).  Everything the encoder kernels need beyond the samples and the
+// codestream -- coefficients, bit lengths, prefix sums, the unstuffed stream, histograms, tables, the state
+// record -- lives in ONE file-scope device array of a fixed, modest size.  Every GPU the library is used on
+// holds its own copy of the array (at its own address) until the process ends; every call on a GPU shares
+// that GPU's array, so calls that overlap on one GPU race.
+#define JH_NOALLOC_BYTES (32u << 20)
+static __device__ __align__(256) unsigned char scratch[JH_NOALLOC_BYTES];
+
+// `scratch` above is, in host code, only a handle for hipGetSymbolAddress(): the device address is looked up
+// once per device (with that device current) and kept here; host code uses these pointers and nothing else.
+#define JH_NOALLOC_MAX_DEVICES 64
+static unsigned char *g_scratch_ptr[JH_NOALLOC_MAX_DEVICES];
+static std::mutex g_scratch_mu;
+
+static int scratch_of_device(int device, unsigned char **ptr)
+{
+	if (device < 0 || device >= JH_NOALLOC_MAX_DEVICES) {
+		return RET_FAILURE_LOGIC_ERROR;
+	}
+	std::lock_guard<std::mutex> lock(g_scratch_mu);
+	if (!g_scratch_ptr[device]) {
+		void *p = nullptr;
+		HIPCHK(hipSetDevice(device));
+		HIPCHK(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+		if (!p) {
+			return RET_FAILURE_LOGIC_ERROR;
+		}
+		g_scratch_ptr[device] = (unsigned char *)p;
+	}
+	*ptr = g_scratch_ptr[device];
+	return RET_SUCCESS;
+}
+
+// what the set-up kernel receives BY VALUE (kernel arguments: no host-to-device copy, no staging buffer)
+struct NoAllocSetup {
+	JhQuant quant;                    // raster order, as jh_launch_encode_pixels() wants it
+	uint8_t hdr[512];                 // [0, pre_len): SOI DQT SOF0; [pre_len, pre_len + suf_len): SOS
+	int pre_len, suf_len;
+	uint8_t L[4][16];                 // the default tables [Tc * 2 + Th] (mjpeg.h), as a DHT segment carries them
+	uint8_t V[4][256];
+	// where things live inside the scratch array
+	uint32_t off_quant, off_state, off_hdr_len, off_hdr, off_specs, off_codes;
+};
+
+__global__ __launch_bounds__(256) void k_noalloc_setup(const NoAllocSetup a, unsigned char *base)
+{
+	const int tid = threadIdx.x;
+	reinterpret_cast<uint16_t *>(base + a.off_quant)[tid] = (&a.quant.q[0][0])[tid];   // 4 x 64 entries
+	for (int i = tid; i < a.pre_len + a.suf_len; i += 256) {
+		(base + a.off_hdr)[i] = a.hdr[i];
+	}
+	if (tid < (int)(sizeof(JhEncState) / 4)) {
+		reinterpret_cast<uint32_t *>(base + a.off_state)[tid] = 0;
+	}
+	JhDevSpec *specs = reinterpret_cast<JhDevSpec *>(base + a.off_specs);
+	JhHuffEnc *codes = reinterpret_cast<JhHuffEnc *>(base + a.off_codes);
+	for (int t = 0; t < 4; ++t) {
+		specs[t].V[tid] = a.V[t][tid];
+		codes[t].code[tid] = 0;
+		if (tid < 16) {
+			specs[t].L[tid] = a.L[t][tid];
+		}
+	}
+	__syncthreads();
+	if (tid < 4) {
+		// Annex C (huffman.c:45-148): canonical codes in table order; a symbol listed twice keeps its first
+		// code (value_to_vlc, huffman.c:238-245)
+		uint32_t code = 0;
+		int p = 0;
+		for (int len = 1; len <= 16; ++len) {
+			for (int i = 0; i < a.L[tid][len - 1] && p < 256; ++i, ++p) {
+				const int sym = a.V[tid][p];
+				if (codes[tid].code[sym] == 0) {
+					codes[tid].code[sym] = (code << 8) | (uint32_t)len;
+				}
+				code++;
+			}
+			code <<= 1;
+		}
+		specs[tid].mt = (uint32_t)p;
+	}
+}
+
+// {RET code, codestream length} for the caller, on the device
+__global__ void k_noalloc_result(const JhEncState *st, const uint32_t *hdr_len, uint32_t *result)
+{
+	uint32_t r = RET_SUCCESS;
+	if (st->first_err != 0) {
+		r = ((~st->first_err) & 1u) ? (uint32_t)JPEG_HIP_ERR_NO_CODE : (uint32_t)JPEG_HIP_ERR_DC_RANGE;
+	} else if (st->status & JH_EST_DC_RANGE) {
+		r = (uint32_t)JPEG_HIP_ERR_DC_RANGE;
+	} else if (st->status & JH_EST_NO_CODE) {
+		r = (uint32_t)JPEG_HIP_ERR_NO_CODE;
+	} else if (st->status & JH_EST_OVERFLOW) {
+		r = RET_FAILURE_OVERFLOW_ERROR;
+	}
+	result[0] = r;
+	result[1] = r ? 0u : hdr_len[0] + st->ecs_bytes + 2u;
+}
+
+extern "C" size_t jpeg_hip_encode_noalloc_limit(void) { return JH_NOALLOC_BYTES; }
+
+// Set-up, once per device (optional: the entry point does it on its first call on a device otherwise).  The
+// HIP runtime loads this library's code object on the device at this point, and the fixed array comes into
+// being with it: a caller that must not see device memory change inside jpeg_hip_encode_noalloc() calls this
+// first, outside its no-allocation region.
+extern "C" int jpeg_hip_encode_noalloc_init(int device)
+{
+	int err = require_device(device);
+	if (err) {
+		return err;
+	}
+	unsigned char *base = nullptr;
+	return scratch_of_device(device, &base);
+}
+
+extern "C" int jpeg_hip_encode_noalloc(int device, const jpeg_hip_params *params, int X, int Y, int Nf, int P,
+                                       const void *d_samples, void *d_jpeg, size_t cap, uint32_t *d_result, void *stream)
+{
+	int err = require_device(device);
+	if (err) {
+		return err;
+	}
+	if (!params || !d_samples || !d_jpeg || !d_result) {
+		return RET_FAILURE_LOGIC_ERROR;
+	}
+	JhGeom g;
+	err = encoder_geometry(X, Y, Nf, P, params, &g);
+	if (err) {
+		return err;
+	}
+	unsigned char *base = nullptr;
+	err = scratch_of_device(device, &base);
+	if (err) {
+		return err;
+	}
+	if (cap < 8192 || cap > 0xffffffffu) {
+		fprintf(stderr, "jpeg_amd: jpeg_hip_encode_noalloc: the codestream buffer must hold 8192 .. 2^32 - 1 bytes (got %zu)\n", cap);
+		return RET_FAILURE_OVERFLOW_ERROR;
+	}
+
+	// ---- carve the array: fixed-size pieces first, the unstuffed stream takes what is left
+	JhEncodeWork w;
+	memset(&w, 0, sizeof w);
+	w.nframes = 1;
+	w.nwg = (g.nblk + 255) / 256;
+	size_t off = 0;
+	auto take = [&](size_t bytes) {
+		const size_t at = off;
+		off = align_up(off + bytes, 256);
+		return at;
+	};
+	NoAllocSetup su;
+	memset(&su, 0, sizeof su);
+	su.off_quant = (uint32_t)take(sizeof(JhQuant));
+	su.off_state = (uint32_t)take(sizeof(JhEncState));
+	su.off_hdr_len = (uint32_t)take(sizeof(uint32_t));
+	su.off_hdr = (uint32_t)take(sizeof su.hdr);
+	su.off_specs = (uint32_t)take(4 * sizeof(JhDevSpec));
+	su.off_codes = (uint32_t)take(4 * sizeof(JhHuffEnc));
+	const size_t off_hist = take(4 * 257 * sizeof(uint32_t));
+	const size_t off_chunk_ff = take((JH_NOALLOC_BYTES / 4096) * sizeof(uint32_t));
+	const size_t off_wg_bits = take((size_t)(w.nwg + 1) * sizeof(uint32_t));
+	const size_t off_bitlen = take((size_t)g.nblk * sizeof(uint16_t));
+	const size_t off_coefs = take((size_t)g.nblk * 64 * sizeof(int16_t));
+	const size_t raw = (size_t)X * Y * Nf * g.sample_bytes;
+	const size_t us_need = align_up(raw + (size_t)g.nblk * 4 + 65536, 4096);    // what jpeg_hip_encoder_configure() reserves
+	if (off + us_need > JH_NOALLOC_BYTES) {
+		fprintf(stderr, "jpeg_amd: jpeg_hip_encode_noalloc: a %dx%d frame of %d component(s) needs %zu bytes of workspace, the "
+		                "fixed array holds %u (use the encoder object)\n", X, Y, Nf, off + us_need, JH_NOALLOC_BYTES);
+		return RET_FAILURE_OVERFLOW_ERROR;
+	}
+	const size_t off_us = off;
+	w.us_stride = (JH_NOALLOC_BYTES - off) / 4096 * 4096;
+	w.nchunk = (int)(w.us_stride / 4096);
+	w.out_stride = cap;
+	w.coefs = reinterpret_cast<int16_t *>(base + off_coefs);
+	w.codes = reinterpret_cast<JhHuffEnc *>(base + su.off_codes);
+	w.hist = reinterpret_cast<uint32_t *>(base + off_hist);
+	w.bitlen = reinterpret_cast<uint16_t *>(base + off_bitlen);
+	w.wg_bits = reinterpret_cast<uint32_t *>(base + off_wg_bits);
+	w.us = reinterpret_cast<uint32_t *>(base + off_us);
+	w.chunk_ff = reinterpret_cast<uint32_t *>(base + off_chunk_ff);
+	w.out = (uint8_t *)d_jpeg;
+	w.hdr_len = reinterpret_cast<uint32_t *>(base + su.off_hdr_len);
+	w.specs = reinterpret_cast<JhDevSpec *>(base + su.off_specs);
+	w.state = reinterpret_cast<JhEncState *>(base + su.off_state);
+	w.ntab = Nf > 1 ? 2 : 1;
+
+	// ---- tables and header bytes, handed to the set-up kernel by value
+	uint16_t Q[4][64];
+	for (int t = 0; t < 4; ++t) {
+		for (int i = 0; i < 64; ++i) {
+			Q[t][i] = 1;
+		}
+	}
+	jh_set_qtable(Q[0], 0, params->q);                     // encoder.c:151-152
+	jh_set_qtable(Q[1], 1, params->q);
+	memcpy(su.quant.q, Q, sizeof Q);
+	JhHuffSpec ht[2][4];
+	for (int tc = 0; tc < 2; ++tc) {
+		for (int th = 0; th < 4; ++th) {
+			jh_default_table(tc, th & 1, &ht[tc][th]);
+		}
+		for (int th = 0; th < 2; ++th) {
+			memcpy(su.L[tc * 2 + th], ht[tc][th].L, 16);
+			memcpy(su.V[tc * 2 + th], ht[tc][th].V, 256);
+		}
+	}
+	std::vector<uint8_t> full;
+	jh_produce_headers(g, Q, ht, 0, &full);
+	size_t pre = 0, suf = 0;
+	if (!split_headers(full, &pre, &suf) || pre + (full.size() - suf) > sizeof su.hdr) {
+		return RET_FAILURE_LOGIC_ERROR;
+	}
+	memcpy(su.hdr, full.data(), pre);
+	memcpy(su.hdr + pre, full.data() + suf, full.size() - suf);
+	su.pre_len = (int)pre;
+	su.suf_len = (int)(full.size() - suf);
+	w.hdr_pre = base + su.off_hdr;
+	w.hdr_pre_len = su.pre_len;
+	w.hdr_suf = base + su.off_hdr + pre;
+	w.hdr_suf_len = su.suf_len;
+
+	hipStream_t s = (hipStream_t)stream;
+	hipLaunchKernelGGL(k_noalloc_setup, dim3(1), dim3(256), 0, s, su, base);
+	if (hipGetLastError() != hipSuccess) {
+		return RET_FAILURE_LOGIC_ERROR;
+	}
+	if (jh_launch_encode_pixels(g, 1, d_samples, raw, reinterpret_cast<const JhQuant *>(base + su.off_quant),
+	                            reinterpret_cast<int16_t *>(base + off_coefs), s)) {
+		return RET_FAILURE_LOGIC_ERROR;
+	}
+	if (params->optimize) {
+		if (jh_launch_enc_histogram(w, g, s, nullptr) || jh_launch_enc_adapt(w, g, s, nullptr)) {
+			return RET_FAILURE_LOGIC_ERROR;
+		}
+	} else if (jh_launch_enc_headers(w, g, s)) {
+		return RET_FAILURE_LOGIC_ERROR;
+	}
+	if (jh_launch_enc_entropy(w, g, s, nullptr)) {
+		return RET_FAILURE_LOGIC_ERROR;
+	}
+	hipLaunchKernelGGL(k_noalloc_result, dim3(1), dim3(1), 0, s, w.state, w.hdr_len, d_result);
+	return hipGetLastError() == hipSuccess ? RET_SUCCESS : RET_FAILURE_LOGIC_ERROR;
 }
 
 // ======================================================================================= single-image drop-ins

@@ -382,6 +382,16 @@ __global__ __launch_bounds__(256) void k_enc_headers(const EncArgs a)
 	}
 }
 
+// the headers alone, from the tables w.specs holds (callers that fill the specs themselves)
+int jh_launch_enc_headers(const JhEncodeWork &w, const JhGeom &g, hipStream_t s)
+{
+	EncArgs a;
+	a.w = w;
+	a.g = g;
+	hipLaunchKernelGGL(k_enc_headers, dim3(w.nframes), dim3(256), 0, s, a);
+	return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 int jh_launch_enc_adapt(const JhEncodeWork &w, const JhGeom &g, hipStream_t s, const JhTimerHook *th)
 {
 	EncArgs a;

@@ -154,4 +154,5 @@ struct JhEncodeWork {
 
 int jh_launch_enc_histogram(const JhEncodeWork &w, const JhGeom &g, hipStream_t s, const JhTimerHook *th);
 int jh_launch_enc_adapt(const JhEncodeWork &w, const JhGeom &g, hipStream_t s, const JhTimerHook *th);
+int jh_launch_enc_headers(const JhEncodeWork &w, const JhGeom &g, hipStream_t s);
 int jh_launch_enc_entropy(const JhEncodeWork &w, const JhGeom &g, hipStream_t s, const JhTimerHook *th);

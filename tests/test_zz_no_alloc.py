@@ -1,0 +1,89 @@
+"""jpeg_hip_encode_noalloc (include/jpeg_amd.h): the encoder for callers that cannot allocate device memory.
+No counterpart in the reference.  Called through the C-ABI on device buffers; its codestream must be the bytes
+jpeg_hip_encoder_run() (the encoder object) produces for the same frame -- which the parity tests pin to the
+oracle -- on two calls in a row, the second with a smaller input (the fixed array keeps the first call's
+contents), in default-table and optimised-table mode, 8- and 12-bit; device memory in use must not change."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from jpeg_amd.synth import synth_image
+from oracle.pyoracle import pnm_body
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from jpeg_amd import binding
+    assert binding.lib().jpeg_hip_device_count() > 0, "no HIP device: the product path has no CPU fallback"
+    # set-up outside the no-allocation region: the code object that holds the fixed array is loaded here
+    assert binding.lib().jpeg_hip_encode_noalloc_init(0) == 0
+    return binding
+
+
+def noalloc(hip, torch, img, P, H, V, q, opt, cap=None):
+    a = np.asarray(img)
+    Y, X = a.shape[:2]
+    Nf = 1 if a.ndim == 2 else 3
+    body = torch.frombuffer(bytearray(pnm_body(a, P)), dtype=torch.uint8).cuda()
+    cap = cap or (X * Y * Nf * 2 + 65536)
+    out = torch.zeros(cap, dtype=torch.uint8, device="cuda")
+    res = torch.full((2,), 0x7fffffff, dtype=torch.int32, device="cuda")
+    prm = hip.Params(H, V, q, opt)
+    free0 = torch.cuda.mem_get_info()[0]
+    err = hip.lib().jpeg_hip_encode_noalloc(0, C.byref(prm), X, Y, Nf, P, C.c_void_p(body.data_ptr()),
+                                            C.c_void_p(out.data_ptr()), cap, C.c_void_p(res.data_ptr()),
+                                            C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] == free0, "device memory in use changed across the call"
+    if err:
+        return err, None, None
+    status, length = (int(v) for v in res.cpu().tolist())
+    return 0, status, bytes(out[:length].cpu().numpy().tobytes())
+
+
+CASES = [
+    # first call (larger), second call (smaller): X, Y, Nf, P, H, V, q, optimize
+    ((640, 360, 3, 8, 2, 2, 90, 0), (200, 120, 3, 8, 2, 2, 90, 0)),
+    ((512, 384, 3, 8, 2, 1, 75, 1), (99, 75, 3, 8, 1, 1, 60, 1)),
+    ((1920, 1080, 3, 8, 1, 1, 85, 1), (97, 33, 1, 8, 1, 1, 50, 0)),
+    ((384, 256, 1, 12, 1, 1, 80, 1), (64, 48, 3, 12, 2, 2, 80, 0)),
+]
+
+
+@pytest.mark.parametrize("first,second", CASES)
+def test_noalloc_matches_the_encoder_object(hip, oracle, first, second):
+    import torch
+    for X, Y, Nf, P, H, V, q, opt in (first, second):
+        img = synth_image(X, Y, Nf, P, seed=77, range_safe=P > 8)
+        want, st = hip.encode([img], P=P, H=H, V=V, q=q, optimize=opt)
+        assert st == [0]
+        err, status, jpg = noalloc(hip, torch, img, P, H, V, q, opt)
+        assert err == 0 and status == 0
+        assert jpg == want[0]
+        if X * Y <= 1 << 18:
+            assert jpg == oracle.encode(img, P=P, H=H, V=V, q=q, optimize=opt)[1]
+
+
+def test_noalloc_limits_and_errors(hip):
+    import torch
+    L = hip.lib()
+    assert L.jpeg_hip_encode_noalloc_limit() == 32 << 20
+    # a 4K frame does not fit the fixed array: refused with a clear error, nothing launched
+    big = np.zeros((2160, 3840, 3), np.uint8)
+    assert noalloc(hip, torch, big, 8, 2, 2, 90, 0)[0] == hip.RET_FAILURE_OVERFLOW_ERROR
+    # a codestream buffer that is too small for this image: the status says so, no out-of-bounds write
+    img = synth_image(256, 256, 3, 8, seed=5)
+    err, status, jpg = noalloc(hip, torch, img, 8, 1, 1, 100, 0, cap=8192)
+    assert err == 0 and status == hip.RET_FAILURE_OVERFLOW_ERROR and jpg == b""
+    assert noalloc(hip, torch, img, 8, 1, 1, 100, 0, cap=100)[0] == hip.RET_FAILURE_OVERFLOW_ERROR
+    # what the reference asserts on: |DC difference| > 2047 (12-bit, full contrast)
+    hard = np.zeros((64, 64), np.uint16)
+    hard[:, 32:] = 4095
+    err, status, _ = noalloc(hip, torch, hard, 12, 1, 1, 100, 0)
+    assert err == 0 and status == hip.JPEG_HIP_ERR_DC_RANGE
+    # and the array still serves the next call
+    want, _ = hip.encode([img], P=8, H=2, V=2, q=75, optimize=1)
+    assert noalloc(hip, torch, img, 8, 2, 2, 75, 1)[2] == want[0]
