@@ -241,7 +241,9 @@ class Decoder:
 
     def sync(self):
         st = (C.c_int * self.n)()
-        self.L.jpeg_hip_decoder_sync(self.h, st)
+        err = self.L.jpeg_hip_decoder_sync(self.h, st)
+        if err and not any(st):
+            raise JpegError(err, "jpeg_hip_decoder_sync")  # failed before any frame status was written
         return list(st)
 
     def stats(self, frame=0):
@@ -350,7 +352,9 @@ class Encoder:
     def sync(self):
         st = (C.c_int * self.n)()
         ln = (C.c_size_t * self.n)()
-        self.L.jpeg_hip_encoder_sync(self.h, st, ln)
+        err = self.L.jpeg_hip_encoder_sync(self.h, st, ln)
+        if err and not any(st):
+            raise JpegError(err, "jpeg_hip_encoder_sync")  # failed before any frame status was written
         return list(st), list(ln)
 
     def jpeg(self, frame, length):

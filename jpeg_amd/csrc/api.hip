@@ -193,7 +193,7 @@ struct DecPass {
 	std::vector<JhHuffLut> luts;
 	size_t cs_off = 0, seg_off = 0, chunk_off = 0, sub_off = 0, wg_off = 0;
 	uint32_t max_chunks = 1, max_subs = 1, max_luts = 1;
-	JhDecodeWork work;
+	JhDecodeWork work{};
 
 	void release()
 	{
@@ -404,7 +404,7 @@ static int decoder_prepare(jpeg_hip_decoder *dec, int nframes, const uint8_t *co
 		HIPCHK(hipStreamSynchronize(dec->last_stream));    // the buffers are about to be reused
 	}
 	dec->ran = false;
-	dec->nframes = nframes;
+	dec->nframes = 0;                                      // not prepared until everything below has succeeded
 	dec->parse_err.assign(nframes, 0);
 	dec->ecs_len.assign(nframes, 0);
 
@@ -740,6 +740,7 @@ static int decoder_prepare(jpeg_hip_decoder *dec, int nframes, const uint8_t *co
 		w.max_luts = ps.max_luts;
 		w.debug = dec->debug;
 	}
+	dec->nframes = nframes;
 	return RET_SUCCESS;
 }
 
@@ -831,6 +832,9 @@ extern "C" int jpeg_hip_decoder_sync(jpeg_hip_decoder *dec, int *frame_status)
 {
 	if (!dec || !dec->ran) {
 		return RET_FAILURE_LOGIC_ERROR;
+	}
+	for (int f = 0; frame_status && f < dec->nframes; ++f) {
+		frame_status[f] = RET_FAILURE_LOGIC_ERROR;         // what every early return below leaves behind
 	}
 	HIPCHK(hipSetDevice(dec->device));
 	HIPCHK(hipStreamSynchronize(dec->last_stream));
@@ -1009,6 +1013,7 @@ struct jpeg_hip_encoder {
 	hipStream_t last_stream = nullptr;
 	bool ran = false;
 	long long alloc_sig[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // what the device buffers were sized for
+	size_t grown_us = 0, grown_out = 0;                  // stream strides after sync() had to grow them (kept while alloc_sig holds)
 	StageTimer timer;
 
 	void release()
@@ -1163,8 +1168,10 @@ static int encoder_configure(jpeg_hip_encoder *enc, int nframes, int X, int Y, i
 	w.nframes = nframes;
 	w.nwg = (g.nblk + 255) / 256;
 	const size_t raw = (size_t)X * Y * Nf * g.sample_bytes;
+	// The unstuffed stream is sized for ordinary images (a little more than the samples themselves); noise at
+	// high quality needs more (up to 64 x 27 bits per block): sync() then grows the streams and codes the
+	// batch once more (encoder_grow_streams).
 	w.us_stride = align_up(raw + (size_t)g.nblk * 4 + 65536, 4096);
-	w.nchunk = (int)(w.us_stride / 4096);
 	w.out_stride = align_up(4096 + w.us_stride + w.us_stride / 8, 4096);
 	w.restart_interval = enc->restart_interval;
 	w.nivl = w.restart_interval > 0 ? (g.nmcu + w.restart_interval - 1) / w.restart_interval : 0;
@@ -1173,8 +1180,17 @@ static int encoder_configure(jpeg_hip_encoder *enc, int nframes, int X, int Y, i
 	// quality, the table mode or nothing at all (a service that reconfigures per batch) keeps the buffers.
 	const long long sig[8] = {nframes, X, Y, Nf, P, g.H[0], g.V[0], w.restart_interval};
 	const bool keep = enc->d_out != nullptr && memcmp(sig, enc->alloc_sig, sizeof sig) == 0;
+	if (keep && enc->grown_us) {
+		w.us_stride = enc->grown_us;
+		w.out_stride = enc->grown_out;
+	}
+	w.nchunk = (int)(w.us_stride / 4096);
+	if (w.us_stride > 0x1ffffff0ull || w.out_stride > 0xfffffff0ull) {
+		return RET_FAILURE_OVERFLOW_ERROR;                 // bit positions and byte offsets of a frame are 32-bit
+	}
 	if (!keep) {
 	enc->release();
+	enc->grown_us = enc->grown_out = 0;
 	memset(enc->alloc_sig, 0, sizeof enc->alloc_sig);      // set again once every buffer is there
 	HIPCHK(hipMalloc((void **)&enc->d_quant, nframes * sizeof(JhQuant)));
 	HIPCHK(hipMalloc((void **)&enc->d_coefs, (size_t)nframes * g.nblk * 64 * sizeof(int16_t)));
@@ -1294,14 +1310,101 @@ extern "C" int jpeg_hip_encoder_run(jpeg_hip_encoder *enc, const void *d_samples
 	return RET_SUCCESS;
 }
 
+// A frame's entropy-coded data did not fit the unstuffed stream or the output slot (noise at high quality: the
+// streams are sized for ordinary images).  The reference writes to a FILE* without limit, so: grow both to
+// what the device counted (the bit total is exact even when it does not fit), worst case for the stuffing,
+// and code the batch once more from the coefficients that are still in HBM.
+static int encoder_grow_streams(jpeg_hip_encoder *enc)
+{
+	JhEncodeWork &w = enc->work;
+	const int n = enc->nframes;
+	uint32_t max_bits = 0;
+	for (int f = 0; f < n; ++f) {
+		max_bits = enc->state[f].total_bits > max_bits ? enc->state[f].total_bits : max_bits;
+	}
+	size_t us = align_up((size_t)max_bits / 8 + (size_t)w.nivl + 65536, 4096);
+	us = us > w.us_stride ? us : w.us_stride;
+	const size_t out = align_up(4096 + 2 * us + 2 * (size_t)w.nivl + 16, 4096);
+	if (us > 0x1ffffff0ull || out > 0xfffffff0ull || (us == w.us_stride && out <= w.out_stride)) {
+		return RET_FAILURE_OVERFLOW_ERROR;
+	}
+	hipFree(enc->d_us);
+	hipFree(enc->d_out);
+	hipFree(enc->d_chunk_ff);
+	enc->d_us = nullptr;
+	enc->d_chunk_ff = nullptr;
+	enc->d_out = nullptr;
+	memset(enc->alloc_sig, 0, sizeof enc->alloc_sig);      // a failure below leaves an encoder that configure() rebuilds
+	w.us_stride = us;
+	w.out_stride = out;
+	w.nchunk = (int)(us / 4096);
+	HIPCHK(hipMalloc((void **)&enc->d_us, (size_t)n * w.us_stride));
+	HIPCHK(hipMalloc((void **)&enc->d_chunk_ff, (size_t)n * w.nchunk * sizeof(uint32_t)));
+	HIPCHK(hipMalloc((void **)&enc->d_out, (size_t)n * w.out_stride));
+	w.us = enc->d_us;
+	w.chunk_ff = enc->d_chunk_ff;
+	w.out = enc->d_out;
+	enc->grown_us = us;
+	enc->grown_out = out;
+	const JhGeom &g = enc->g;
+	const long long sig[8] = {n, g.X, g.Y, g.Nf, g.P, g.H[0], g.V[0], w.restart_interval};
+	memcpy(enc->alloc_sig, sig, sizeof sig);
+	// the state records keep what the pixel and statistics stages found; the stream totals start again
+	for (int f = 0; f < n; ++f) {
+		enc->state[f].status &= ~(uint32_t)JH_EST_OVERFLOW;
+		enc->state[f].total_bits = enc->state[f].us_bytes = enc->state[f].ecs_bytes = 0;
+	}
+	hipStream_t s = enc->last_stream;
+	HIPCHK(hipMemcpy(enc->d_state, enc->state.data(), n * sizeof(JhEncState), hipMemcpyHostToDevice));
+	if (enc->prm.optimize) {
+		if (jh_launch_enc_adapt(w, g, s, nullptr)) {       // the statistics are still there: tables and headers again
+			return RET_FAILURE_LOGIC_ERROR;
+		}
+	} else {
+		int err = upload_codes_and_headers(enc, 0, n, s);
+		if (err) {
+			return err;
+		}
+	}
+	if (jh_launch_enc_entropy(w, g, s, nullptr)) {
+		return RET_FAILURE_LOGIC_ERROR;
+	}
+	return RET_SUCCESS;
+}
+
 extern "C" int jpeg_hip_encoder_sync(jpeg_hip_encoder *enc, int *frame_status, size_t *jpg_len)
 {
 	if (!enc || !enc->ran) {
 		return RET_FAILURE_LOGIC_ERROR;
 	}
+	for (int f = 0; f < enc->nframes; ++f) {               // what every early return below leaves behind
+		if (frame_status) {
+			frame_status[f] = RET_FAILURE_LOGIC_ERROR;
+		}
+		if (jpg_len) {
+			jpg_len[f] = 0;
+		}
+	}
 	HIPCHK(hipSetDevice(enc->device));
-	HIPCHK(hipStreamSynchronize(enc->last_stream));
-	HIPCHK(hipMemcpy(enc->state.data(), enc->d_state, enc->nframes * sizeof(JhEncState), hipMemcpyDeviceToHost));
+	for (int attempt = 0;; ++attempt) {
+		HIPCHK(hipStreamSynchronize(enc->last_stream));
+		HIPCHK(hipMemcpy(enc->state.data(), enc->d_state, enc->nframes * sizeof(JhEncState), hipMemcpyDeviceToHost));
+		bool over = false;
+		for (int f = 0; f < enc->nframes; ++f) {
+			const JhEncState &st = enc->state[f];
+			over = over || (st.first_err == 0 && !(st.status & (JH_EST_DC_RANGE | JH_EST_NO_CODE)) && (st.status & JH_EST_OVERFLOW));
+		}
+		if (!over || attempt > 0) {
+			break;
+		}
+		const int err = encoder_grow_streams(enc);
+		if (err == RET_FAILURE_OVERFLOW_ERROR) {
+			break;                                         // beyond what a frame may hold: reported per frame below
+		}
+		if (err) {
+			return err;
+		}
+	}
 	if (enc->prm.optimize) {
 		HIPCHK(hipMemcpy(enc->hdr_len.data(), enc->d_hdr_len, enc->nframes * sizeof(uint32_t), hipMemcpyDeviceToHost));
 	}

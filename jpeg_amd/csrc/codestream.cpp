@@ -521,6 +521,12 @@ static int parse_segments(Reader &r, JhHeader *h, bool *eoi)
 			continue;
 		}
 		if (m == 0xffc0 || m == 0xffc1) {                      // SOF0 / SOF1, decoder.c:70-136
+			if (have_sof) {
+				// A second frame header.  The reference allocates new buffers and goes on (decoder.c:529-543);
+				// scans already described here keep the component indices and tables of the first one, so a
+				// change of the frame under them is refused instead of reinterpreted.
+				return RET_FAILURE_FILE_UNSUPPORTED;
+			}
 			if (!r.ok(8)) {
 				return RET_FAILURE_FILE_IO;
 			}

@@ -595,3 +595,49 @@ def test_device_side_image_generator_matches_the_host_one(hip):
         want = pnm_body(synth_image(X, Y, nc, P, seed, safe, frame=fr), P)
         got = synth_body_torch(X, Y, nc, P, seed, safe, frame=fr, device="cuda:0").cpu().numpy().tobytes()
         assert got == want, (X, Y, nc, P)
+
+
+@pytest.mark.parametrize("P,opt", [(8, 0), (8, 1), (12, 1)])
+def test_noise_at_top_quality_outgrows_the_stream_buffers(hip, oracle, P, opt):
+    """Uniform noise at q = 100 codes to MORE bytes than the samples take: the encoder's unstuffed stream and
+    output slots are sized for ordinary images, sync() grows them and codes the batch again.  The reference
+    writes to a FILE* without limit, so the bytes must simply be the oracle's.  Second frame of the batch: an
+    ordinary image (its stream must survive the second pass unchanged)."""
+    rng = np.random.default_rng(1000 + P)
+    X, Y = 1280, 1024
+    if P == 8:
+        noise = rng.integers(0, 256, (Y, X)).astype(np.uint8)
+    else:
+        # full-contrast noise with every block's mean at mid-grey: |DC difference| stays below 2047 (quirk Q3)
+        n = rng.integers(-1800, 1800, (Y // 8, 8, X // 8, 8))
+        n = n - n.mean(axis=(1, 3), keepdims=True).astype(np.int64)
+        noise = (2048 + n).reshape(Y, X).clip(0, 4095).astype(np.uint16)
+    calm = synth_image(X, Y, 1, 8, seed=3)
+    if P == 12:
+        calm = (2048 + calm.astype(np.int32) - 128).astype(np.uint16)    # DC within +-2047 at Q = 1 as well
+    nblk = (X // 8) * (Y // 8)
+    e = hip.Encoder(0)
+    try:
+        for rounds in range(2):                            # the second configure() keeps the grown buffers
+            e.configure(2, X, Y, 1, P, 1, 1, 100, opt)
+            e.run(e.upload([noise, calm]))
+            st, ln = e.sync()
+            assert st == [0, 0]
+            for f, im in enumerate((noise, calm)):
+                err, want, _ = oracle.encode(im, P=P, H=1, V=1, q=100, optimize=opt)
+                assert err == 0
+                assert e.jpeg(f, ln[f]) == want
+            if P == 8 and opt == 0:
+                # more than configure() reserves (api.hip: raw + 4 bytes per block + 64 KiB): the second pass ran
+                assert ln[0] > X * Y + nblk * 4 + 65536 + 4096
+    finally:
+        e.close()
+    # the stage-level call goes through the same growth
+    if P == 8 and opt == 0:
+        err, want, info = oracle.encode(noise, P=P, H=1, V=1, q=100, optimize=opt)
+        fd = hip.frame_desc(X, Y, P, [1], [1], [0])
+        sd = hip.scan_desc([0], [0], [0])
+        dc = hip.htables([oracle.default_table(0, 0)] + [None] * 3)
+        ac = hip.htables([oracle.default_table(1, 0)] + [None] * 3)
+        err, ecs = hip.write_scan(fd, sd, dc, ac, 0, [info.comps[0]["coef"]])
+        assert err == 0 and ecs in want
