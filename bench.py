@@ -41,6 +41,9 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md, ch
 STREAM_FRAMES = 10000          # BASELINE.json configs[4]: Motion JPEG 1080p 4:2:2 q85, 10k frames
 
 
+HOST_SYNTH = 0                 # --host-synth N: N distinct frames from the numpy generator, repeated (rocprofv3 --pmc runs)
+
+
 def make_batch(torch, binding, synth, name, nframes, device, restart_interval=0):
     """nframes DISTINCT synthetic frames, generated on the device (jpeg_amd.synth.synth_body_torch: the
     integer-only recipe of SURVEY 8d, bit-identical to the numpy generator the parity tests use)
@@ -48,7 +51,13 @@ def make_batch(torch, binding, synth, name, nframes, device, restart_interval=0)
     oracle, tests/), configuration)."""
     X, Y, nc, P, H, V, q, opt, safe, seed = synth.CONFIGS[name]
     dev = "cuda:%d" % device
-    samples = torch.stack([synth.synth_body_torch(X, Y, nc, P, seed, safe, frame=i, device=dev) for i in range(nframes)])
+    if HOST_SYNTH:
+        body = lambda a: a.astype(np.uint8).tobytes() if P <= 8 else a.astype(">u2").tobytes()
+        base = [torch.frombuffer(bytearray(body(synth.synth_image(X, Y, nc, P, seed, safe, frame=i))), dtype=torch.uint8)
+                for i in range(min(HOST_SYNTH, nframes))]
+        samples = torch.stack([base[i % len(base)] for i in range(nframes)]).to(dev)
+    else:
+        samples = torch.stack([synth.synth_body_torch(X, Y, nc, P, seed, safe, frame=i, device=dev) for i in range(nframes)])
     enc = binding.Encoder(device)
     enc.configure(nframes, X, Y, nc, P, H, V, q, opt, restart_interval)
     enc.run(samples)
@@ -330,6 +339,9 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-mjpeg", action="store_true")
     ap.add_argument("--no-workloads", action="store_true", help="skip the C2..C5 lines")
+    ap.add_argument("--host-synth", type=int, default=0,
+                    help="make only this many distinct frames, on the host, and repeat them (rocprofv3 --pmc runs: the "
+                         "counter collection of ROCm 7.2 crashes inside torch's int64 kernels of the device-side generator)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; gloo rehearses the multi-rank path "
                                                       "with several ranks on ONE GPU (RCCL refuses that)")
     ap.add_argument("--one-stream", action="store_true",
@@ -339,6 +351,8 @@ def main():
     if args.cpu_worker > 0:
         cpu_worker(args.cpu_worker)
         return
+    global HOST_SYNTH
+    HOST_SYNTH = args.host_synth
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
 
@@ -406,7 +420,7 @@ def main():
         "dtype_detail": "pixel kernels: binary32 DCT / quantisation and binary64 colour maths, bit-exact with the reference; "
                         "entropy kernels: u8 / int16 / u32 integer work",
         "config": {"workload": "metric_4k_420_q90: 3840x2160 8-bit 4:2:0 q90, default Huffman tables, no restart markers",
-                   "frames_per_gpu_per_step": F, "distinct_frames": F,
+                   "frames_per_gpu_per_step": F, "distinct_frames": min(F, HOST_SYNTH) if HOST_SYNTH else F,
                    "parallelism": "frames sharded over %d GPU(s), no collectives" % world},
         "decode_mpix_s": round(world * F * pix * args.steps / t_d / 1e6, 1),
         "encode_mpix_s": round(world * F * pix * args.steps / t_e / 1e6, 1),

@@ -87,6 +87,14 @@ const char *jpeg_hip_version(void);
  * inside the headers.  tolerant: see jpeg_hip_decoder_set_tolerant(). */
 int jpeg_hip_parse_info(const uint8_t *jpg, size_t len, int tolerant, jpeg_hip_frame_info *info);
 
+/* Self-test of the quantiser's arithmetic (no counterpart in the reference: quantize_block() simply writes
+ * roundf(f / Q), imgproc.c:28).  The encode kernel splits the binary32 division into a per-table-entry part and
+ * a per-coefficient part and rounds by add-and-truncate; this runs both against the compiler's `/` and roundf()
+ * on the device for EVERY divisor 1 .. 65535, numerators on and next to `ties_per_divisor` rounding ties each
+ * plus pseudo-random ones.  out[0] = cases tried, out[1] = quotients that differ (where at least one is >= 0.25 in
+ * magnitude), out[2] = rounded results that differ.  Both must be zero. */
+int jpeg_hip_selftest_divide(int device, int ties_per_divisor, unsigned seed, unsigned long long out[3]);
+
 /* ---- batch decoder ------------------------------------------------------------------------
  * One decoder object owns the device workspace for a batch of frames that share geometry
  * (Motion JPEG: every frame is an independent SOI..EOI codestream, decoder.c:603-612).

@@ -1480,6 +1480,28 @@ extern "C" int jpeg_hip_encoder_get_timing(jpeg_hip_encoder *enc, const char **n
 	return enc->timer.collect(names, ms, cap);
 }
 
+// ======================================================================================= self-test
+
+extern "C" int jpeg_hip_selftest_divide(int device, int ties_per_divisor, unsigned seed, unsigned long long out[3])
+{
+	int err = require_device(device);
+	if (err) {
+		return err;
+	}
+	if (!out || ties_per_divisor < 1) {
+		return RET_FAILURE_LOGIC_ERROR;
+	}
+	unsigned long long *d = nullptr;
+	HIPCHK(hipMalloc((void **)&d, 3 * sizeof *d));
+	hipError_t e = hipMemset(d, 0, 3 * sizeof *d);
+	if (e == hipSuccess && jh_launch_selftest_divide(d, ties_per_divisor, seed, nullptr)) {
+		e = hipErrorUnknown;
+	}
+	e = e == hipSuccess ? hipMemcpy(out, d, 3 * sizeof *d, hipMemcpyDeviceToHost) : e;
+	hipFree(d);
+	return e == hipSuccess ? RET_SUCCESS : RET_FAILURE_LOGIC_ERROR;
+}
+
 // ======================================================================================= no-allocation entry point
 
 // jpeg_hip_encode_noalloc(): jpeg_hip_encoder_run() for ONE frame without any device allocation.  No

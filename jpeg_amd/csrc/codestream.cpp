@@ -201,92 +201,6 @@ int jh_build_enccodes(const JhHuffSpec *s, JhHuffEnc *e)
 	return RET_SUCCESS;
 }
 
-// ---- Annex K.2 ----------------------------------------------------------------------------------
-
-void jh_adapt_table(const uint64_t freq_in[257], JhHuffSpec *s)
-{
-	uint64_t freq[257];
-	int codesize[257], others[257], bits[33];
-
-	memcpy(freq, freq_in, sizeof freq);
-	for (int i = 0; i < 257; ++i) {
-		codesize[i] = 0;
-		others[i] = -1;
-	}
-	for (;;) {                                                 // Figure K.1, huffman.c:366-411
-		int v1 = -1, v2 = -1;
-		uint64_t best = ~(uint64_t)0;
-		for (int i = 0; i < 257; ++i) {                        // ties -> largest index (huffman.c:338)
-			if (freq[i] > 0 && freq[i] <= best) {
-				best = freq[i];
-				v1 = i;
-			}
-		}
-		best = ~(uint64_t)0;
-		for (int i = 0; i < 257; ++i) {
-			if (freq[i] > 0 && freq[i] <= best && i != v1) {
-				best = freq[i];
-				v2 = i;
-			}
-		}
-		if (v2 < 0) {
-			break;
-		}
-		freq[v1] += freq[v2];
-		freq[v2] = 0;
-		for (;; v1 = others[v1]) {
-			codesize[v1]++;
-			if (others[v1] < 0) {
-				break;
-			}
-		}
-		others[v1] = v2;
-		for (;; v2 = others[v2]) {
-			codesize[v2]++;
-			if (others[v2] < 0) {
-				break;
-			}
-		}
-	}
-	memset(bits, 0, sizeof bits);                              // Figure K.2, huffman.c:446-474
-	for (int i = 0; i < 257; ++i) {
-		if (codesize[i] > 0 && codesize[i] <= 32) {
-			bits[codesize[i]]++;
-		}
-	}
-	for (int i = 32; i > 16;) {                                // Figure K.3, huffman.c:413-444
-		if (bits[i] > 0) {
-			int j = i - 1;
-			do {
-				j--;
-			} while (bits[j] <= 0);
-			bits[i] -= 2;
-			bits[i - 1] += 1;
-			bits[j + 1] += 2;
-			bits[j] -= 1;
-		} else {
-			i--;
-		}
-	}
-	int top = 16;
-	while (bits[top] == 0) {
-		top--;
-	}
-	bits[top]--;
-	memset(s, 0, sizeof *s);                                   // Figure K.4, huffman.c:476-506
-	int k = 0;
-	for (int sz = 1; sz <= 32; ++sz) {
-		for (int v = 0; v < 256; ++v) {
-			if (codesize[v] == sz && k < 256) {
-				s->V[k++] = (uint8_t)v;
-			}
-		}
-	}
-	for (int i = 0; i < 16; ++i) {
-		s->L[i] = (uint8_t)bits[i + 1];
-	}
-}
-
 // ---- geometry -----------------------------------------------------------------------------------
 
 int jh_finish_geometry(JhGeom *g)

@@ -42,7 +42,6 @@ void jh_set_qtable(uint16_t Q[64], int chroma, int q);                // encoder
 int  jh_split_stream(const uint8_t *p, size_t n, size_t *off, size_t *len, int cap);   // Motion JPEG frame splitter
 int  jh_build_declut(const JhHuffSpec *s, int tc, JhHuffLut *lut);            // huffman.c:45-148 -> decode tables
 int  jh_build_enccodes(const JhHuffSpec *s, JhHuffEnc *e);            // huffman.c:228-253 first-match codes
-void jh_adapt_table(const uint64_t freq[257], JhHuffSpec *s);         // huffman.c:330-537 (Annex K.2)
 
 // SOI, DQT.., SOF0, DHT.., [DRI], SOS  (encoder.c:195-400, order of produce_codestream :589-645)
 void jh_produce_headers(const JhGeom &g, const uint16_t Q[4][64], const JhHuffSpec ht[2][4],

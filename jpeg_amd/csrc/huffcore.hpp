@@ -6,8 +6,8 @@
 //     k = z + run;  coefficient k <- value;  z = k + 1;  z >= 64 ends the block
 // covers DC (z = 0, run = 0), (run, size) pairs, ZRL (run 15, category 0) and EOB without branches.
 // The bit stream is read through a small interface: RegStream (a queue of words in registers,
-// refilled by one 16-byte global load per four words, a quad ahead), LdsStream (staged window, kept
-// behind -DJH_LDS_STREAM for comparison) or GlobalStream (plain word loads, careful paths).  The bit
+// refilled by one 16-byte global load per four words, a quad ahead) or GlobalStream (plain word loads,
+// careful paths).  The bit
 // window is three 32-bit words in registers, and the NEXT symbol's table look-up is issued before
 // the current symbol's value is extracted, so no load sits on the symbol-to-symbol critical path
 // except that look-up.
@@ -42,35 +42,6 @@ __device__ __forceinline__ unsigned long long pack_state(const DecState &s)
 }
 
 // ---- bit-stream sources -------------------------------------------------------------------------
-
-// a window of the unstuffed stream staged in LDS as big-endian-corrected words; one padding word per
-// 32 (= one sub-sequence) so that lanes reading the same word of neighbouring sub-sequences hit
-// different banks
-struct LdsStream {
-	const uint32_t *sw;
-	uint32_t wbase;                   // stream word held by sw[0]
-	__device__ __forceinline__ uint32_t word(uint32_t w) const
-	{
-		const uint32_t x = w - wbase;
-		return sw[x + (x >> 5)];
-	}
-	struct Cursor {
-		uint32_t x2;                  // index (relative to wbase) of the word after the window
-	};
-	__device__ __forceinline__ void open(Cursor &cur, uint32_t wi, uint32_t &w0, uint32_t &w1, uint32_t &w2) const
-	{
-		cur.x2 = wi + 2 - wbase;
-		w0 = word(wi);
-		w1 = word(wi + 1);
-		w2 = sw[cur.x2 + (cur.x2 >> 5)];
-	}
-	// the window moved on by one word (cross) or stayed: the word that now follows it
-	__device__ __forceinline__ uint32_t next(Cursor &cur, bool cross, uint32_t) const
-	{
-		cur.x2 += cross ? 1u : 0u;
-		return sw[cur.x2 + (cur.x2 >> 5)];
-	}
-};
 
 struct GlobalStream {
 	const uint8_t *cs;
@@ -139,23 +110,6 @@ struct RegStream {
 		return a;
 	}
 };
-
-// cooperative fill of an LdsStream window: words [wbase, wbase + nwords) of cs (16-byte vector loads)
-__device__ __forceinline__ void stage_stream(uint32_t *sw, const uint8_t *cs, uint32_t wbase, uint32_t nwords)
-{
-	const uint4 *src = reinterpret_cast<const uint4 *>(cs + (size_t)wbase * 4);   // wbase is a multiple of 32
-	for (uint32_t q = threadIdx.x; q * 4 < nwords; q += blockDim.x) {
-		const uint4 v = src[q];
-		const uint32_t x = q * 4;
-		uint32_t *d = sw + x + (x >> 5);          // the 4 words of a quad never straddle a padding slot
-		d[0] = __builtin_bswap32(v.x);
-		d[1] = __builtin_bswap32(v.y);
-		d[2] = __builtin_bswap32(v.z);
-		d[3] = __builtin_bswap32(v.w);
-	}
-}
-
-#define JH_STREAM_LDS_WORDS(nsubseq) ((nsubseq) * 33 + 8)
 
 // per-thread DC accumulators live in LDS as [component][thread]: one ds_add per DC symbol instead
 // of a select chain over four registers

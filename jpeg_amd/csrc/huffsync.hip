@@ -257,7 +257,6 @@ __global__ __launch_bounds__(256) void k_huff_chains(const HuffArgs a)
 {
 	extern __shared__ __align__(16) unsigned char smem[];
 	unsigned char *luts = smem;
-	uint32_t *sw = reinterpret_cast<uint32_t *>(smem + sizeof(JhHuffLut) * a.w.max_luts);
 	__shared__ DecTables tb;
 	// LDS decides how many workgroups share a CU, and this kernel's time follows the number of waves in flight
 	// (measured: 12 instead of 16 waves per CU cost 21 %): the arrays of the chain steps and the path records of
@@ -304,15 +303,7 @@ __global__ __launch_bounds__(256) void k_huff_chains(const HuffArgs a)
 	const int tid = threadIdx.x;
 	const int range_len = (int)min(256u, nsub - j0);      // own + ghost sub-sequences of this workgroup
 	JhSubInfo *rec = w.rec + (size_t)(fr.sub_off + j0) * (KMAX + 1);
-#ifdef JH_LDS_STREAM
-	LdsStream S;
-	S.sw = sw;
-	S.wbase = j0 * (JH_SUBSEQ_BITS / 32);
-	stage_stream(sw, cs, S.wbase, (uint32_t)range_len * (JH_SUBSEQ_BITS / 32) + 4);
-#else
-	(void)sw;
 	const RegStream S{cs};
-#endif
 	int *mydcs = &dcs[0][tid];
 
 	// ---- step 0: every chain decodes its own sub-sequence -------------------------------------
@@ -914,11 +905,7 @@ int jh_launch_huff_sync(const JhDecodeWork &w, const JhGeom &g, hipStream_t s, c
 	a.g = g;
 	a.round = 0;
 	const size_t lds = sizeof(JhHuffLut) * (size_t)w.max_luts;
-#ifdef JH_LDS_STREAM
-	const size_t lds_chains = lds + JH_STREAM_LDS_WORDS(256) * sizeof(uint32_t);
-#else
 	const size_t lds_chains = lds;
-#endif
 	const unsigned nwg = jh_num_chain_wgs(w.max_subs);
 	// static + dynamic LDS of this kernel exceeds the 64 KB default limit
 	if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_huff_chains), hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -101,6 +101,8 @@ int jh_launch_decode_pixels(const JhGeom &g, int nframes, const int16_t *coefs, 
 int jh_launch_encode_pixels(const JhGeom &g, int nframes, const void *in, size_t frame_stride,
                             const JhQuant *quant_raster, int16_t *coefs, hipStream_t stream);
 
+int jh_launch_selftest_divide(unsigned long long *d_out, int per, unsigned seed, hipStream_t stream);
+
 // ---- entropy encoder -------------------------------------------------------------------------------
 
 enum {                            // JhEncState.status bits

@@ -25,13 +25,22 @@
 // Work decomposition.  One workgroup = a run of G MCUs of one MCU row (about 96 blocks); the
 // tile lives in LDS as one float plane per component AT COMPONENT RESOLUTION, 8*V rows of
 // G*8*H (+4) floats.  All stages are "tasks" strided over the 256 threads:
-//   decode: A  (block, zig-zag octet): one coalesced 16-byte load, dequantise, scatter to raster
-//           B  (block, row)   : 1-D inverse transform of a row in 16 VGPRs (packed f32 maths)
+//   decode: A  (block, zig-zag octet): one coalesced 16-byte load, parked as it is in LDS (the int16 lines
+//              of the tile's blocks lie over the float planes, which are not in use yet)
+//           B  (block, row)   : the row's 8 coefficients picked out of the block's zig-zag line, dequantised,
+//              1-D inverse transform of the row in 16 VGPRs (packed f32 maths); written to the planes
+//              once every thread has read its coefficients
 //           C  (block, column): 1-D inverse transform of a column, + level shift
 //           D  (row, 4 pixels): replication up-sampling, colour maths, 12/24-byte coalesced store
 //   encode: 1  (row group, 4 pixels): coalesced sample load, RGB -> YCbCr, box mean, level shift
-//           2/3 row / column forward transform, column pass quantises in place
-//           4  (block, zig-zag octet): gather, pack int16, one coalesced 16-byte store
+//           2  (block, row): forward transform of a row
+//           3  (block, column): forward transform of a column, quantisation; the results go, as int16, to
+//              their zig-zag places in the blocks' 128-byte lines, which lie over the float planes (written
+//              once every thread has read its column)
+//           4  (block, zig-zag octet): one 16-byte LDS read, one coalesced 16-byte store
+// A thread's place inside its block (row / column / octet = tid & 7) is the same in every round of a stage
+// (the rounds are 256 threads apart), so everything that depends on it -- zig-zag places, the block's LDS
+// address -- is worked out once per thread.
 // 8 threads share a block, so a wave holds 16 live values per lane instead of 128: occupancy is
 // bounded by LDS (about 25 KB per workgroup), not by VGPRs.
 #include <hip/hip_runtime.h>
@@ -84,10 +93,45 @@ __device__ __forceinline__ void dct1(const float (&in)[8], float (&out)[8])
 	}
 }
 
+#ifndef TILE_BLOCKS
+#define TILE_BLOCKS 96
+#endif
+#define TILE_ROUNDS ((TILE_BLOCKS * 8 + 255) / 256)   // rounds of a (block, 1/8 block) stage over 256 threads
+
+// (int)roundf(x) for |x| < 2^31: adding the largest float below one half (with the sign of x) and
+// truncating gives round-half-away-from-zero for EVERY float (checked exhaustively on the host,
+// tests/test_round_cpu.py); adding 0.5 itself would not (0.49999997 + 0.5 rounds to 1).
+__device__ __forceinline__ int round_half_away(float x)
+{
+	return (int)(x + __builtin_copysignf(0x1.fffffep-2f, x));
+}
+
+// quantize_block() divides in binary32 (imgproc.c:28).  hipcc expands `n / d` into a reciprocal estimate, one
+// Newton step on it, the quotient estimate and two correction steps (all FMAs), wrapped in scaling
+// (v_div_scale) and a fix-up (v_div_fixup) for operands near the ends of the exponent range.  The first three
+// steps depend on the divisor only and are done once per table entry (quant_reciprocal); with |n| < 2^24 and
+// 1 <= d <= 65535 the scaling and fix-up steps are the identity unless the quotient is far below 0.5, where
+// the rounding to an integer cannot see a difference, so quant_divide() gives the correctly rounded quotient
+// wherever it matters.  jpeg_hip_selftest_divide() checks exactly that against the compiler's own `/` for
+// every divisor (tests/test_gpu_stages.py).
+__device__ __forceinline__ float quant_reciprocal(float d)
+{
+	const float r0 = __builtin_amdgcn_rcpf(d);
+	const float e0 = __builtin_fmaf(-d, r0, 1.0f);
+	return __builtin_fmaf(e0, r0, r0);
+}
+
+__device__ __forceinline__ float quant_divide(float n, float d, float r1)
+{
+	const float q0 = n * r1;
+	const float q1 = __builtin_fmaf(__builtin_fmaf(-d, q0, n), r1, q0);
+	return __builtin_fmaf(__builtin_fmaf(-d, q1, n), r1, q1);
+}
+
 // ---- tile layout (host computed, shared by both kernels) -----------------------------------------
 struct TileLayout {
 	int G;                              // MCUs per workgroup
-	unsigned b_magic;                   // floor(2^32 / B) + 1: mcu = umulhi(block, b_magic)
+	unsigned b_magic16;                 // floor(2^16 / B) + 1: mcu = (block * b_magic16) >> 16 for block < 2^16 / B
 	int TW, TH;                         // tile size in frame pixels
 	unsigned qpr_magic;                 // floor(2^32 / (TW/4)) + 1
 	int base[JH_MAX_COMP], pitch[JH_MAX_COMP];          // component planes in LDS (floats)
@@ -102,14 +146,11 @@ struct TileLayout {
 static void make_layout(const JhGeom &g, TileLayout *t)
 {
 	memset(t, 0, sizeof *t);
-#ifndef TILE_BLOCKS
-#define TILE_BLOCKS 96
-#endif
 	int G = TILE_BLOCKS / g.B;
 	G = G < 1 ? 1 : G;
 	G = G > g.m_x ? g.m_x : G;
 	t->G = G;
-	t->b_magic = (unsigned)(0x100000000ull / (unsigned)g.B) + 1u;
+	t->b_magic16 = 65536u / (unsigned)g.B + 1u;
 	t->TW = G * 8 * g.max_H;
 	t->TH = 8 * g.max_V;
 	t->qpr_magic = (unsigned)(0x100000000ull / (unsigned)(t->TW / 4)) + 1u;
@@ -141,6 +182,7 @@ struct BlockTask {
 struct KTab {
 	int koff[JH_MAX_MCU_BLOCKS], kpitch[JH_MAX_MCU_BLOCKS], kmst[JH_MAX_MCU_BLOCKS], ktq[JH_MAX_MCU_BLOCKS];
 	uint32_t zig[8][2];                 // 8 raster indices (one byte each) per zig-zag octet
+	uint8_t invz[64];                   // raster index -> zig-zag position
 };
 
 __device__ __forceinline__ void stage_ktab(KTab &kt, const TileLayout &L, int B, int tid)
@@ -161,15 +203,19 @@ __device__ __forceinline__ void stage_ktab(KTab &kt, const TileLayout &L, int B,
 		kt.zig[j][0] = lo;
 		kt.zig[j][1] = hi;
 	}
+	if (tid >= 128 && tid < 192) {
+		kt.invz[kZig[tid - 128]] = (uint8_t)(tid - 128);
+	}
 }
 
 __device__ __forceinline__ BlockTask block_task(const KTab &kt, const TileLayout &L, int B, int b)
 {
-	const int mcu = B == 1 ? b : (int)__umulhi((unsigned)b, L.b_magic);   // 2^32 / 1 does not fit
-	const int k = b - mcu * B;
+	// b < 128 blocks per tile, B <= 10: 24-bit multiplies (full rate) are exact
+	const int mcu = B == 1 ? b : (int)(__umul24((unsigned)b, L.b_magic16) >> 16);
+	const int k = b - (int)__umul24((unsigned)mcu, (unsigned)B);
 	BlockTask r;
 	r.pitch = kt.kpitch[k];
-	r.addr = kt.koff[k] + mcu * kt.kmst[k];
+	r.addr = kt.koff[k] + (int)__umul24((unsigned)mcu, (unsigned)kt.kmst[k]);
 	r.tq = kt.ktq[k];
 	return r;
 }
@@ -219,7 +265,7 @@ template <int NF, int CSX>
 __global__ __launch_bounds__(256) void k_decode_pixels(const DecPixArgs a)
 {
 	extern __shared__ __align__(16) float tile[];
-	__shared__ uint16_t sq[4][64];
+	__shared__ __align__(16) uint16_t sq[4][64];       // quantisation tables in RASTER order
 	__shared__ KTab kt;
 
 	const JhGeom &g = a.g;
@@ -229,63 +275,92 @@ __global__ __launch_bounds__(256) void k_decode_pixels(const DecPixArgs a)
 	const int B = g.B;
 	const int nmcu_here = min(L.G, g.m_x - mx0);
 	const int ntask = nmcu_here * B * 8;
+	const int sub = tid & 7;                          // this thread's octet / row / column in every round
 
 	for (int i = tid; i < 4 * 64; i += 256) {
-		sq[i >> 6][i & 63] = a.quant[f].q[i >> 6][i & 63];
+		sq[i >> 6][kZig[i & 63]] = a.quant[f].q[i >> 6][i & 63];
 	}
 	stage_ktab(kt, L, B, tid);
-	__syncthreads();
 
-	// ---- A: (block, zig-zag octet): load, dequantise, scatter to raster order -------------------
+	// ---- A: (block, zig-zag octet): the blocks' 128-byte lines as they are, parked over the planes ----
 	{
 		const int4 *src = reinterpret_cast<const int4 *>(
 			a.coefs + ((size_t)f * g.nblk + (size_t)(my * g.m_x + mx0) * B) * 64);
-		for (int t = tid; t < ntask; t += 256) {
-			const int b = t >> 3, j = t & 7;
-			const BlockTask bt = block_task(kt, L, B, b);
-			const int4 w = src[t];
-			const uint32_t zlo = kt.zig[j][0], zhi = kt.zig[j][1];
-			const uint16_t *q = &sq[bt.tq][j * 8];
-			const int ws[4] = {w.x, w.y, w.z, w.w};
+		int4 *stg = reinterpret_cast<int4 *>(tile);
 #pragma unroll
-			for (int e = 0; e < 8; ++e) {
-				const int cv = (e & 1) ? (ws[e >> 1] >> 16) : (int)(short)(ws[e >> 1] & 0xffff);
-				const int r = (int)(((e < 4 ? zlo : zhi) >> (8 * (e & 3))) & 0xff);
-				// dequantize_block: int32 product, then int -> float (imgproc.c:17)
-				tile[bt.addr + (r >> 3) * bt.pitch + (r & 7)] = (float)(cv * (int)q[e]);
+		for (int it = 0; it < TILE_ROUNDS; ++it) {
+			const int t = tid + it * 256;
+			if (t < ntask) {
+				stg[t] = src[t];
 			}
 		}
 	}
 	__syncthreads();
 
-	// ---- B: (block, row): rows first (imgproc.c:134-140) ----------------------------------------
-	for (int t = tid; t < ntask; t += 256) {
-		const BlockTask bt = block_task(kt, L, B, t >> 3);
-		float4 *p = reinterpret_cast<float4 *>(tile + bt.addr + (t & 7) * bt.pitch);
-		const float4 v0 = p[0], v1 = p[1];
-		const float in[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-		float o[8];
-		dct1<true>(in, o);
-		p[0] = make_float4(o[0], o[1], o[2], o[3]);
-		p[1] = make_float4(o[4], o[5], o[6], o[7]);
+	BlockTask bts[TILE_ROUNDS];
+#pragma unroll
+	for (int it = 0; it < TILE_ROUNDS; ++it) {
+		const int t = tid + it * 256;
+		bts[it] = block_task(kt, L, B, (t < ntask ? t : 0) >> 3);
+	}
+
+	// ---- B: (block, row): dequantize_block (imgproc.c:17), rows first (imgproc.c:134-140) ---------
+	{
+		int zrow[8];                                  // zig-zag places of raster row `sub`
+#pragma unroll
+		for (int x = 0; x < 8; ++x) {
+			zrow[x] = kt.invz[sub * 8 + x];
+		}
+		float rowv[TILE_ROUNDS][8];
+#pragma unroll
+		for (int it = 0; it < TILE_ROUNDS; ++it) {
+			const int t = tid + it * 256;
+			if (t < ntask) {
+				const int16_t *line = reinterpret_cast<const int16_t *>(tile) + (t >> 3) * 64;
+				const uint4 qw = *reinterpret_cast<const uint4 *>(&sq[bts[it].tq][sub * 8]);
+				const unsigned qs[4] = {qw.x, qw.y, qw.z, qw.w};
+				float in[8];
+#pragma unroll
+				for (int x = 0; x < 8; ++x) {
+					const int q = (int)((x & 1) ? (qs[x >> 1] >> 16) : (qs[x >> 1] & 0xffffu));
+					// int32 product, then int -> float; |c| < 2^15 and q < 2^16: the 24-bit multiply is exact
+					in[x] = (float)__mul24((int)line[zrow[x]], q);
+				}
+				dct1<true>(in, rowv[it]);
+			}
+		}
+		__syncthreads();                              // every coefficient has been read: the planes may be written
+#pragma unroll
+		for (int it = 0; it < TILE_ROUNDS; ++it) {
+			const int t = tid + it * 256;
+			if (t < ntask) {
+				float4 *p = reinterpret_cast<float4 *>(tile + bts[it].addr + sub * bts[it].pitch);
+				p[0] = make_float4(rowv[it][0], rowv[it][1], rowv[it][2], rowv[it][3]);
+				p[1] = make_float4(rowv[it][4], rowv[it][5], rowv[it][6], rowv[it][7]);
+			}
+		}
 	}
 	__syncthreads();
 
 	// ---- C: (block, column): then columns (imgproc.c:142-148), level shift (imgproc.c:192-194) ---
 	{
 		const float shiftf = (float)(1 << (g.P - 1));
-		for (int t = tid; t < ntask; t += 256) {
-			const BlockTask bt = block_task(kt, L, B, t >> 3);
-			float *p = tile + bt.addr + (t & 7);
-			float in[8], o[8];
 #pragma unroll
-			for (int u = 0; u < 8; ++u) {
-				in[u] = p[u * bt.pitch];
-			}
-			dct1<true>(in, o);
+		for (int it = 0; it < TILE_ROUNDS; ++it) {
+			const int t = tid + it * 256;
+			if (t < ntask) {
+				const int pitch = bts[it].pitch;
+				float *p = tile + bts[it].addr + sub;
+				float in[8], o[8];
 #pragma unroll
-			for (int y = 0; y < 8; ++y) {
-				p[y * bt.pitch] = o[y] + shiftf;
+				for (int u = 0; u < 8; ++u) {
+					in[u] = p[u * pitch];
+				}
+				dct1<true>(in, o);
+#pragma unroll
+				for (int y = 0; y < 8; ++y) {
+					p[y * pitch] = o[y] + shiftf;
+				}
 			}
 		}
 	}
@@ -295,7 +370,7 @@ __global__ __launch_bounds__(256) void k_decode_pixels(const DecPixArgs a)
 	const int qpr = L.TW >> 2;                // quads per tile row
 	const int X = g.X, Y = g.Y;
 	constexpr int oc = NF == 1 ? 1 : 3;
-	const int maxval = (1 << g.P) - 1;
+	const float maxvalf = (float)((1 << g.P) - 1);
 	const int shift = 1 << (g.P - 1);
 	const int denom = 1 << g.P;
 	(void)denom;
@@ -344,11 +419,10 @@ __global__ __launch_bounds__(256) void k_decode_pixels(const DecPixArgs a)
 			}
 #pragma unroll
 			for (int c = 0; c < oc; ++c) {
-				// (int)roundf(x) clamped to [0, maxval] (frame.c:375-380): negative values end at 0 whatever
-				// their rounding; for x >= 0 half away from zero is floor(x) + (fract(x) >= 0.5)
-				const float y = fmaxf(o[c], 0.f);
-				const unsigned iv = (unsigned)y + (__builtin_amdgcn_fractf(y) >= 0.5f ? 1u : 0u);
-				res[i * oc + c] = (int)min(iv, (unsigned)maxval);
+				// (int)roundf(x) clamped to [0, maxval] (frame.c:375-380).  Rounding is monotonic and the bounds
+				// are integers, so clamping first gives the same sample; then round_half_away() on x >= 0
+				const float y = __builtin_amdgcn_fmed3f(o[c], 0.f, maxvalf);
+				res[i * oc + c] = (int)(y + 0x1.fffffep-2f);
 			}
 		}
 		const int npx = min(4, X - gx0);
@@ -503,12 +577,8 @@ __global__ __launch_bounds__(256) void k_encode_pixels(const EncPixArgs a)
 	const uint8_t *inf = a.in + (size_t)f * a.frame_stride;
 
 	for (int i = tid; i < 4 * 64; i += 256) {
-		// the first three steps of the correctly rounded fp32 division (the expansion hipcc emits for `/`):
-		// reciprocal estimate and one Newton step; they depend on the divisor only
 		const float d = (float)a.quant[f].q[i >> 6][i & 63];
-		const float r0 = __builtin_amdgcn_rcpf(d);
-		const float e0 = __builtin_fmaf(-d, r0, 1.0f);
-		sqf[i >> 6][i & 63] = make_float2(d, __builtin_fmaf(e0, r0, r0));
+		sqf[i >> 6][i & 63] = make_float2(d, quant_reciprocal(d));
 	}
 	stage_ktab(kt, L, B, tid);
 
@@ -584,63 +654,85 @@ __global__ __launch_bounds__(256) void k_encode_pixels(const EncPixArgs a)
 	}
 	__syncthreads();
 
+	BlockTask bts[TILE_ROUNDS];
+	const int sub = tid & 7;                          // this thread's row / column / octet in every round
+#pragma unroll
+	for (int it = 0; it < TILE_ROUNDS; ++it) {
+		const int t = tid + it * 256;
+		bts[it] = block_task(kt, L, B, (t < ntask ? t : 0) >> 3);
+	}
+
 	// ---- 2: (block, row): rows first (imgproc.c:155-161) -----------------------------------------
-	for (int t = tid; t < ntask; t += 256) {
-		const BlockTask bt = block_task(kt, L, B, t >> 3);
-		float4 *p = reinterpret_cast<float4 *>(tile + bt.addr + (t & 7) * bt.pitch);
-		const float4 v0 = p[0], v1 = p[1];
-		const float in[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-		float o[8];
-		dct1<false>(in, o);
-		p[0] = make_float4(o[0], o[1], o[2], o[3]);
-		p[1] = make_float4(o[4], o[5], o[6], o[7]);
+#pragma unroll
+	for (int it = 0; it < TILE_ROUNDS; ++it) {
+		const int t = tid + it * 256;
+		if (t < ntask) {
+			float4 *p = reinterpret_cast<float4 *>(tile + bts[it].addr + sub * bts[it].pitch);
+			const float4 v0 = p[0], v1 = p[1];
+			const float in[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+			float o[8];
+			dct1<false>(in, o);
+			p[0] = make_float4(o[0], o[1], o[2], o[3]);
+			p[1] = make_float4(o[4], o[5], o[6], o[7]);
+		}
 	}
 	__syncthreads();
 
 	// ---- 3: (block, column): columns (imgproc.c:163-169), then quantize_block (imgproc.c:28) -------
-	for (int t = tid; t < ntask; t += 256) {
-		const BlockTask bt = block_task(kt, L, B, t >> 3);
-		const int x = t & 7;
-		float *p = tile + bt.addr + x;
-		const float2 *q = &sqf[bt.tq][x];
-		float in[8], o[8];
-#pragma unroll
-		for (int y = 0; y < 8; ++y) {
-			in[y] = p[y * bt.pitch];
-		}
-		dct1<false>(in, o);
+	{
+		int zcol[8];                                  // zig-zag places of raster column `sub`
 #pragma unroll
 		for (int u = 0; u < 8; ++u) {
-			// IEEE divide, round half away from zero.  o / d as the rest of the division's expansion: with
-			// operands in this range (|o| < 2^24, 1 <= d <= 65535) the scaling and fix-up steps of the
-			// general sequence are the identity unless the quotient is far below 0.5, where the rounding
-			// cannot see a difference; the arithmetic that decides every other case is the same, so the
-			// quotient is the correctly rounded one.
-			const float d = q[u * 8].x, r1 = q[u * 8].y, n = o[u];
-			const float q0 = n * r1;
-			const float q1 = __builtin_fmaf(__builtin_fmaf(-d, q0, n), r1, q0);
-			const float qq = __builtin_fmaf(__builtin_fmaf(-d, q1, n), r1, q1);
-			p[u * bt.pitch] = __int_as_float((int)roundf(qq));
+			zcol[u] = kt.invz[u * 8 + sub];
+		}
+		int iq[TILE_ROUNDS][8];
+#pragma unroll
+		for (int it = 0; it < TILE_ROUNDS; ++it) {
+			const int t = tid + it * 256;
+			if (t < ntask) {
+				const int pitch = bts[it].pitch;
+				const float *p = tile + bts[it].addr + sub;
+				const float2 *q = &sqf[bts[it].tq][sub];
+				float in[8], o[8];
+#pragma unroll
+				for (int y = 0; y < 8; ++y) {
+					in[y] = p[y * pitch];
+				}
+				dct1<false>(in, o);
+#pragma unroll
+				for (int u = 0; u < 8; ++u) {
+					// IEEE divide, round half away from zero (imgproc.c:28)
+					const float qq = quant_divide(o[u], q[u * 8].x, q[u * 8].y);
+					iq[it][u] = round_half_away(qq);
+				}
+			}
+		}
+		__syncthreads();                              // every column has been read: the blocks' int16 lines go over the planes
+#pragma unroll
+		for (int it = 0; it < TILE_ROUNDS; ++it) {
+			const int t = tid + it * 256;
+			if (t < ntask) {
+				uint16_t *line = reinterpret_cast<uint16_t *>(tile) + (t >> 3) * 64;
+#pragma unroll
+				for (int u = 0; u < 8; ++u) {
+					line[zcol[u]] = (uint16_t)iq[it][u];
+				}
+			}
 		}
 	}
 	__syncthreads();
 
-	// ---- 4: (block, zig-zag octet): gather, pack, store -------------------------------------------
+	// ---- 4: (block, zig-zag octet): the finished lines, 16 bytes per thread, coalesced ------------
 	{
 		int4 *dst = reinterpret_cast<int4 *>(
 			a.coefs + ((size_t)f * g.nblk + (size_t)(my * g.m_x + mx0) * B) * 64);
-		for (int t = tid; t < ntask; t += 256) {
-			const int j = t & 7;
-			const BlockTask bt = block_task(kt, L, B, t >> 3);
-			const uint32_t zlo = kt.zig[j][0], zhi = kt.zig[j][1];
-			int cv[8];
+		const int4 *stg = reinterpret_cast<const int4 *>(tile);
 #pragma unroll
-			for (int e = 0; e < 8; ++e) {
-				const int r = (int)(((e < 4 ? zlo : zhi) >> (8 * (e & 3))) & 0xff);
-				cv[e] = __float_as_int(tile[bt.addr + (r >> 3) * bt.pitch + (r & 7)]);
+		for (int it = 0; it < TILE_ROUNDS; ++it) {
+			const int t = tid + it * 256;
+			if (t < ntask) {
+				dst[t] = stg[t];
 			}
-			dst[t] = make_int4((cv[0] & 0xffff) | (cv[1] << 16), (cv[2] & 0xffff) | (cv[3] << 16),
-			                   (cv[4] & 0xffff) | (cv[5] << 16), (cv[6] & 0xffff) | (cv[7] << 16));
 		}
 	}
 }
@@ -679,5 +771,60 @@ int jh_launch_encode_pixels(const JhGeom &g, int nframes, const void *in, size_t
 	} else {
 		return -1;   // jpeg_hip_encoder_configure() admits nothing else (encoder.c:123-124)
 	}
+	return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// ================================================================================== self-test
+
+// quant_divide() and round_half_away() against the compiler's own division and roundf(), for EVERY divisor
+// 1 .. 65535: numerators around every rounding tie (k + 0.5) * d that fits 2^24, k stepping so that about
+// `per` ties per divisor are visited, each with its float neighbours, plus pseudo-random numerators.
+// out[0] = cases, out[1] = quotients that differ while not both far below 0.5, out[2] = rounded results that differ
+__global__ __launch_bounds__(256) void k_selftest_divide(unsigned long long *out, int per, unsigned seed)
+{
+	const int d_i = blockIdx.x * 256 + threadIdx.x + 1;
+	if (d_i > 65535) {
+		return;
+	}
+	const float d = (float)d_i, r1 = quant_reciprocal(d);
+	unsigned long long cases = 0, badq = 0, badr = 0;
+	const int kmax = (int)(16777216.0f / d);
+	const int step = kmax / per + 1;
+	unsigned h = seed ^ (unsigned)d_i * 0x9E3779B1u;
+	for (int k = 0; k <= kmax; k += step) {
+		const float tie = ((float)k + 0.5f) * d;
+		for (int nb = -2; nb <= 2; ++nb) {
+			for (int sgn = 0; sgn < 2; ++sgn) {
+				float n = __int_as_float(__float_as_int(tie) + nb);
+				n = sgn ? -n : n;
+				const float want = n / d, got = quant_divide(n, d, r1);
+				cases++;
+				if (want != got && !(fabsf(want) < 0.25f && fabsf(got) < 0.25f)) {
+					badq++;
+				}
+				if ((int)roundf(want) != round_half_away(got)) {
+					badr++;
+				}
+			}
+		}
+		h = h * 1664525u + 1013904223u;
+		const float n = (float)((int)(h >> 7) - (1 << 24)) * 0.5f;     // |n| < 2^24, halves included
+		const float want = n / d, got = quant_divide(n, d, r1);
+		cases++;
+		if (want != got && !(fabsf(want) < 0.25f && fabsf(got) < 0.25f)) {
+			badq++;
+		}
+		if ((int)roundf(want) != round_half_away(got)) {
+			badr++;
+		}
+	}
+	atomicAdd(&out[0], cases);
+	atomicAdd(&out[1], badq);
+	atomicAdd(&out[2], badr);
+}
+
+int jh_launch_selftest_divide(unsigned long long *d_out, int per, unsigned seed, hipStream_t stream)
+{
+	hipLaunchKernelGGL(k_selftest_divide, dim3(256), dim3(256), 0, stream, d_out, per, seed);
 	return hipGetLastError() == hipSuccess ? 0 : -1;
 }

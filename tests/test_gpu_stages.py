@@ -6,6 +6,7 @@ parse_format() / produce_codestream(): read_ecs (decoder.
 (decoder.c:456-470), prologue (encoder.c:176-193), write_ecs_dry + write_ecs (encoder.c:525-587).  The
 marker walk below plays the part of parse_format(); every stage result is compared bit for bit with what the
 oracle holds at the same stage boundary."""
+import ctypes as C
 import json
 import os
 
@@ -196,3 +197,15 @@ def test_stage_error_behaviour(hip, oracle):
     # a scan that names a component twice
     twice = hip.scan_desc([0, 0], [0, 0], [0, 0])
     assert hip.read_scan(fd, twice, dc, ac, jpg[begin:])[0] == hip.RET_FAILURE_FILE_UNSUPPORTED
+
+
+def test_quantiser_division_against_the_compilers_own(hip):
+    """quantize_block() is roundf(f / Q) in binary32 (imgproc.c:28).  The encode kernel hoists the divisor-only
+    steps of hipcc's division expansion into the table and rounds by add-and-truncate (pixels.hip: quant_divide,
+    round_half_away); jpeg_hip_selftest_divide runs both against `/` and roundf() on the device for every
+    divisor 1 .. 65535, on and beside the rounding ties and on random numerators."""
+    out = (C.c_ulonglong * 3)()
+    for seed, per in ((1, 400), (2, 97)):
+        assert hip.lib().jpeg_hip_selftest_divide(0, per, seed, out) == 0
+        cases, badq, badr = (int(v) for v in out)
+        assert cases > 50_000_000 and badq == 0 and badr == 0, (cases, badq, badr)

@@ -17,7 +17,7 @@ def main():
     F = int(sys.argv[2]) if len(sys.argv) > 2 else 16
     reps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
     torch.cuda.set_device(0)
-    enc, samples, jpgs, imgs, cfg = bench.make_batch(binding, synth, name, F, 0)
+    enc, samples, jpgs, cfg = bench.make_batch(torch, binding, synth, name, F, 0)
     dec = binding.Decoder(0)
     dec.prepare(jpgs)
     out = dec.alloc_output()
