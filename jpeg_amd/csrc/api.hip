@@ -1007,24 +1007,27 @@ struct jpeg_hip_encoder {
 	uint32_t *d_hist = nullptr, *d_wg_bits = nullptr, *d_us = nullptr, *d_chunk_ff = nullptr, *d_hdr_len = nullptr;
 	uint32_t *d_ivl_raw = nullptr, *d_ivl_padsum = nullptr, *d_ivl_eb = nullptr;
 	uint16_t *d_bitlen = nullptr;
+	unsigned long long *d_nzmap = nullptr;
+	uint32_t *d_acdc = nullptr;
 	uint8_t *d_out = nullptr;
 	JhEncState *d_state = nullptr;
 	JhEncodeWork work;
 	hipStream_t last_stream = nullptr;
 	bool ran = false;
 	long long alloc_sig[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // what the device buffers were sized for
+	bool acbits_ready = false;                           // the last run's pixel kernel filled d_nzmap / d_acdc (default tables)
 	size_t grown_us = 0, grown_out = 0;                  // stream strides after sync() had to grow them (kept while alloc_sig holds)
 	StageTimer timer;
 
 	void release()
 	{
 		hipFree(d_quant); hipFree(d_coefs); hipFree(d_codes); hipFree(d_hist); hipFree(d_wg_bits);
-		hipFree(d_us); hipFree(d_chunk_ff); hipFree(d_hdr_len); hipFree(d_bitlen); hipFree(d_out); hipFree(d_state);
+		hipFree(d_us); hipFree(d_chunk_ff); hipFree(d_hdr_len); hipFree(d_bitlen); hipFree(d_nzmap); hipFree(d_acdc); hipFree(d_out); hipFree(d_state);
 		hipFree(d_ivl_raw); hipFree(d_ivl_padsum); hipFree(d_ivl_eb); hipFree(d_specs); hipFree(d_hdr_parts);
 		d_specs = nullptr; d_hdr_parts = nullptr;
 		d_ivl_raw = d_ivl_padsum = d_ivl_eb = nullptr;
 		d_quant = nullptr; d_coefs = nullptr; d_codes = nullptr; d_hist = d_wg_bits = d_us = d_chunk_ff = d_hdr_len = nullptr;
-		d_bitlen = nullptr; d_out = nullptr; d_state = nullptr;
+		d_bitlen = nullptr; d_nzmap = nullptr; d_acdc = nullptr; d_out = nullptr; d_state = nullptr;
 	}
 };
 
@@ -1201,6 +1204,8 @@ static int encoder_configure(jpeg_hip_encoder *enc, int nframes, int X, int Y, i
 	HIPCHK(hipMalloc((void **)&enc->d_chunk_ff, (size_t)nframes * w.nchunk * sizeof(uint32_t)));
 	HIPCHK(hipMalloc((void **)&enc->d_hdr_len, nframes * sizeof(uint32_t)));
 	HIPCHK(hipMalloc((void **)&enc->d_bitlen, (size_t)nframes * g.nblk * sizeof(uint16_t)));
+	HIPCHK(hipMalloc((void **)&enc->d_nzmap, (size_t)nframes * g.nblk * sizeof(unsigned long long)));
+	HIPCHK(hipMalloc((void **)&enc->d_acdc, (size_t)nframes * g.nblk * sizeof(uint32_t)));
 	HIPCHK(hipMalloc((void **)&enc->d_out, (size_t)nframes * w.out_stride));
 	HIPCHK(hipMalloc((void **)&enc->d_state, nframes * sizeof(JhEncState)));
 	if (w.nivl > 0) {
@@ -1237,6 +1242,8 @@ static int encoder_configure(jpeg_hip_encoder *enc, int nframes, int X, int Y, i
 	w.codes = enc->d_codes;
 	w.hist = enc->d_hist;
 	w.bitlen = enc->d_bitlen;
+	w.nzmap = enc->d_nzmap;
+	w.acdc = enc->d_acdc;
 	w.wg_bits = enc->d_wg_bits;
 	w.us = enc->d_us;
 	w.chunk_ff = enc->d_chunk_ff;
@@ -1292,7 +1299,10 @@ extern "C" int jpeg_hip_encoder_run(jpeg_hip_encoder *enc, const void *d_samples
 	HIPCHK(hipMemsetAsync(enc->d_state, 0, enc->nframes * sizeof(JhEncState), s));
 	const JhTimerHook th = enc->timer.hook();
 	enc->timer.begin("k_encode_pixels", s);
-	if (jh_launch_encode_pixels(g, enc->nframes, d_samples, frame_stride, enc->d_quant, enc->d_coefs, s)) {
+	// default tables: the codes are known, and the pixel kernel counts every block's AC bits while it holds the block
+	const bool acbits = !enc->prm.optimize;
+	if (jh_launch_encode_pixels(g, enc->nframes, d_samples, frame_stride, enc->d_quant, enc->d_coefs, enc->d_nzmap, enc->d_acdc,
+	                            acbits ? enc->d_codes : nullptr, s)) {
 		return RET_FAILURE_LOGIC_ERROR;
 	}
 	enc->timer.end(s);
@@ -1303,9 +1313,10 @@ extern "C" int jpeg_hip_encoder_run(jpeg_hip_encoder *enc, const void *d_samples
 			return RET_FAILURE_LOGIC_ERROR;
 		}
 	}
-	if (jh_launch_enc_entropy(w, g, s, &th)) {
+	if (jh_launch_enc_entropy(w, g, s, &th, acbits)) {
 		return RET_FAILURE_LOGIC_ERROR;
 	}
+	enc->acbits_ready = acbits;
 	enc->ran = true;
 	return RET_SUCCESS;
 }
@@ -1366,7 +1377,7 @@ static int encoder_grow_streams(jpeg_hip_encoder *enc)
 			return err;
 		}
 	}
-	if (jh_launch_enc_entropy(w, g, s, nullptr)) {
+	if (jh_launch_enc_entropy(w, g, s, nullptr, enc->acbits_ready)) {
 		return RET_FAILURE_LOGIC_ERROR;
 	}
 	return RET_SUCCESS;
@@ -1670,6 +1681,8 @@ extern "C" int jpeg_hip_encode_noalloc(int device, const jpeg_hip_params *params
 	const size_t off_chunk_ff = take((JH_NOALLOC_BYTES / 4096) * sizeof(uint32_t));
 	const size_t off_wg_bits = take((size_t)(w.nwg + 1) * sizeof(uint32_t));
 	const size_t off_bitlen = take((size_t)g.nblk * sizeof(uint16_t));
+	const size_t off_nzmap = take((size_t)g.nblk * sizeof(unsigned long long));
+	const size_t off_acdc = take((size_t)g.nblk * sizeof(uint32_t));
 	const size_t off_coefs = take((size_t)g.nblk * 64 * sizeof(int16_t));
 	const size_t raw = (size_t)X * Y * Nf * g.sample_bytes;
 	const size_t us_need = align_up(raw + (size_t)g.nblk * 4 + 65536, 4096);    // what jpeg_hip_encoder_configure() reserves
@@ -1686,6 +1699,8 @@ extern "C" int jpeg_hip_encode_noalloc(int device, const jpeg_hip_params *params
 	w.codes = reinterpret_cast<JhHuffEnc *>(base + su.off_codes);
 	w.hist = reinterpret_cast<uint32_t *>(base + off_hist);
 	w.bitlen = reinterpret_cast<uint16_t *>(base + off_bitlen);
+	w.nzmap = reinterpret_cast<unsigned long long *>(base + off_nzmap);
+	w.acdc = reinterpret_cast<uint32_t *>(base + off_acdc);
 	w.wg_bits = reinterpret_cast<uint32_t *>(base + off_wg_bits);
 	w.us = reinterpret_cast<uint32_t *>(base + off_us);
 	w.chunk_ff = reinterpret_cast<uint32_t *>(base + off_chunk_ff);
@@ -1736,7 +1751,7 @@ extern "C" int jpeg_hip_encode_noalloc(int device, const jpeg_hip_params *params
 		return RET_FAILURE_LOGIC_ERROR;
 	}
 	if (jh_launch_encode_pixels(g, 1, d_samples, raw, reinterpret_cast<const JhQuant *>(base + su.off_quant),
-	                            reinterpret_cast<int16_t *>(base + off_coefs), s)) {
+	                            reinterpret_cast<int16_t *>(base + off_coefs), w.nzmap, w.acdc, params->optimize ? nullptr : w.codes, s)) {
 		return RET_FAILURE_LOGIC_ERROR;
 	}
 	if (params->optimize) {
@@ -1746,7 +1761,7 @@ extern "C" int jpeg_hip_encode_noalloc(int device, const jpeg_hip_params *params
 	} else if (jh_launch_enc_headers(w, g, s)) {
 		return RET_FAILURE_LOGIC_ERROR;
 	}
-	if (jh_launch_enc_entropy(w, g, s, nullptr)) {
+	if (jh_launch_enc_entropy(w, g, s, nullptr, !params->optimize)) {
 		return RET_FAILURE_LOGIC_ERROR;
 	}
 	hipLaunchKernelGGL(k_noalloc_result, dim3(1), dim3(1), 0, s, w.state, w.hdr_len, d_result);
@@ -2018,7 +2033,7 @@ extern "C" int jpeg_hip_encode_pixels(int device, const jpeg_hip_frame_desc *fra
 		const size_t body = (size_t)g.X * g.Y * g.Nf * g.sample_bytes;
 		if (hipMalloc(&d_in, body) != hipSuccess || hipMemcpy(d_in, samples, body, hipMemcpyHostToDevice) != hipSuccess) {
 			err = RET_FAILURE_MEMORY_ALLOCATION;
-		} else if (jh_launch_encode_pixels(g, 1, d_in, body, enc->d_quant, enc->d_coefs, nullptr) ||
+		} else if (jh_launch_encode_pixels(g, 1, d_in, body, enc->d_quant, enc->d_coefs, nullptr, nullptr, nullptr, nullptr) ||
 		           hipStreamSynchronize(nullptr) != hipSuccess) {
 			err = RET_FAILURE_LOGIC_ERROR;
 		}
@@ -2135,7 +2150,7 @@ extern "C" int jpeg_hip_write_scan(int device, const jpeg_hip_frame_desc *frame,
 	const JhGeom &g = enc->g;
 	const JhEncodeWork &w = enc->work;
 	if ((optimize && (jh_launch_enc_histogram(w, g, nullptr, nullptr) || jh_launch_enc_adapt(w, g, nullptr, nullptr))) ||
-	    jh_launch_enc_entropy(w, g, nullptr, nullptr)) {
+	    jh_launch_enc_entropy(w, g, nullptr, nullptr, false)) {
 		err = RET_FAILURE_LOGIC_ERROR;
 	}
 	if (!err) {

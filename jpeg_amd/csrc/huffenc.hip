@@ -8,8 +8,11 @@
 // by data-parallel stages over the int16 scan-order coefficient buffer:
 //
 //   k_enc_histogram  symbol statistics per table (LDS histograms, one global atomic per used bin)
-//   k_enc_bitlen     bits per block (Figure F.2 walk with the table's code sizes) + workgroup sums,
-//                    plus the two conditions the reference assert()s / fails on
+//   k_enc_dcbits     default tables: the pixel kernel has already counted the bits of every block's AC symbols
+//                    (while the block was in LDS); this adds the DC symbol (its predictor lives in
+//                    another block), the workgroup sums and the two conditions the reference assert()s / fails on
+//   k_enc_bitlen     optimised tables or coefficients from the caller: the same from the coefficients
+//                    (Figure F.2 walk with the table's code sizes), nonzero maps and DC values written on the way
 //   k_enc_wg_scan    exclusive scan of the workgroup sums = bit offset of every 256-block group
 //   k_enc_pack       every thread re-walks its block and ORs its code words into an LDS image of the
 //                    workgroup's bit range (MSB first); the image is stored coalesced, the two shared
@@ -90,6 +93,41 @@ __device__ __forceinline__ int dc_predictor(const int16_t *frame_coefs, int blk,
 	}
 	const int last = g.comp_first[comp] + g.H[comp] * g.V[comp] - 1;
 	return frame_coefs[((size_t)(mcu - 1) * g.B + last) * 64];
+}
+
+// the same from the per-block records (no 128-byte line touched for two bytes)
+__device__ __forceinline__ int dc_predictor_info(const uint32_t *acdc, int blk, const JhGeom &g, int ri)
+{
+	const int mcu = blk / g.B, k = blk - mcu * g.B;
+	const int comp = g.blk_comp[k];
+	if (k > g.comp_first[comp]) {
+		return (int)acdc[blk - 1] >> 16;
+	}
+	if (mcu == 0 || (ri > 0 && mcu % ri == 0)) {
+		return 0;
+	}
+	const int last = g.comp_first[comp] + g.H[comp] * g.V[comp] - 1;
+	return (int)acdc[(size_t)(mcu - 1) * g.B + last] >> 16;
+}
+
+// bit 0: the low int16 of d is nonzero, bit 1: the high one
+__device__ __forceinline__ unsigned nz_pair(int d)
+{
+	typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+	const us2 one = {1, 1};
+	const unsigned x = __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(us2, d), one));
+	return (x | (x >> 15)) & 3u;
+}
+
+__device__ __forceinline__ unsigned long long block_nzmap(const BlockRegs &b)
+{
+	unsigned lo = 0, hi = 0;
+#pragma unroll
+	for (int i = 0; i < 16; ++i) {
+		lo |= nz_pair(b.w[i]) << (2 * i);
+		hi |= nz_pair(b.w[16 + i]) << (2 * i);
+	}
+	return ((unsigned long long)hi << 32) | lo;
 }
 
 // Figure F.2 (coeffs.c:276-306): calls sym(rs, cat, extra) for every AC symbol of the block.
@@ -483,6 +521,52 @@ __global__ __launch_bounds__(256) void k_enc_bitlen(const EncArgs a)
 			bits += s + (unsigned)cat;
 		});
 		w.bitlen[(size_t)f * g.nblk + blk] = (uint16_t)bits;
+		w.nzmap[(size_t)f * g.nblk + blk] = block_nzmap(b);
+		w.acdc[(size_t)f * g.nblk + blk] = (uint32_t)coef_at(b, 0) << 16;
+	}
+	if (err) {
+		atomicOr(&w.state[f].status, err);
+		// inside a block the range test comes first (encoder.c:447 before write_block)
+		atomicMax(&w.state[f].first_err, ~((uint32_t)blk * 2u + ((err & JH_EST_DC_RANGE) ? 0u : 1u)));
+	}
+	const unsigned total = block_sum(bits, scratch);
+	if (threadIdx.x == 0) {
+		w.wg_bits[(size_t)f * (w.nwg + 1) + blockIdx.x] = total;
+	}
+}
+
+// Default tables: the AC part of every block's length is in JhBlkInfo already (pixel kernel).  The DC symbol
+// (write_dc, coeffs.c:110-126) needs the previous block of the component (encoder.c:443-458): added here,
+// with the workgroup sums and the error conditions, from 4 bytes per block instead of 128.
+__global__ __launch_bounds__(256) void k_enc_dcbits(const EncArgs a)
+{
+	__shared__ uint8_t dcsz[2][16];
+	__shared__ unsigned scratch[4];
+	const JhEncodeWork &w = a.w;
+	const JhGeom &g = a.g;
+	const int f = blockIdx.y;
+	if (threadIdx.x < 32) {
+		dcsz[threadIdx.x >> 4][threadIdx.x & 15] = (uint8_t)(w.codes[(size_t)f * 4 + (threadIdx.x >> 4)].code[threadIdx.x & 15] & 0xffu);
+	}
+	__syncthreads();
+	const int blk = blockIdx.x * 256 + threadIdx.x;
+	const uint32_t *acdc = w.acdc + (size_t)f * g.nblk;
+	unsigned bits = 0, err = 0;
+	if (blk < g.nblk) {
+		const uint32_t r = acdc[blk];
+		const unsigned acbits = r & 0xffffu;
+		const int comp = g.blk_comp[blk % g.B];
+		const int diff = ((int)r >> 16) - dc_predictor_info(acdc, blk, g, w.restart_interval);
+		if (diff < -2047 || diff > 2047) {
+			err |= JH_EST_DC_RANGE;                        // assert (encoder.c:447)
+		}
+		const int dcat = category(diff) & 15;
+		const unsigned ds = dcsz[g.Td[comp] & 1][dcat];
+		if (ds == 0 || acbits == JH_ACBITS_NOCODE) {
+			err |= JH_EST_NO_CODE;                         // value_to_vlc() == -1 (huffman.c:252)
+		}
+		bits = ds + (unsigned)dcat + (acbits == JH_ACBITS_NOCODE ? 0u : acbits);
+		w.bitlen[(size_t)f * g.nblk + blk] = (uint16_t)bits;
 	}
 	if (err) {
 		atomicOr(&w.state[f].status, err);
@@ -630,19 +714,11 @@ __global__ __launch_bounds__(256) void k_enc_ivl_scan(const EncArgs a)
 
 // ---------------------------------------------------------------------------------------- bit packing
 
-// bit 0: the low int16 of d is nonzero, bit 1: the high one
-__device__ __forceinline__ unsigned nz_pair(int d)
-{
-	typedef unsigned short us2 __attribute__((ext_vector_type(2)));
-	const us2 one = {1, 1};
-	const unsigned x = __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(us2, d), one));
-	return (x | (x >> 15)) & 3u;
-}
-
 // what a thread reads from global memory for one group of 256 blocks
 struct PackIn {
 	int4 chunk[8];                    // 16-byte pieces j * 256 + tid of the group's coefficients
 	uint32_t r0, r1;                  // the group's bit range
+	unsigned long long nz;            // nonzero map of this thread's block
 	unsigned mylen, mypad;            // bits of this thread's block (padding of its restart interval included)
 	int pred;                         // DC predictor of this thread's block
 	uint32_t kt;                      // its ktab entry
@@ -683,13 +759,15 @@ __device__ __forceinline__ void pack_fetch(const EncArgs &a, const uint32_t *kta
 	asm volatile("" : "+v"(gi));
 	in.r0 = wg[gi];
 	in.r1 = wg[gi + 1];
+	const uint32_t *acdc = w.acdc + (size_t)f * nblk;
 	in.mylen = in.have ? w.bitlen[(size_t)f * nblk + blk] : 0u;
+	in.nz = in.have ? w.nzmap[(size_t)f * nblk + blk] : 0ull;
 	const int mcu = blk / B, k = blk - mcu * B;
 	const uint32_t kt = ktab[in.have ? k : 0];
 	in.kt = kt;
 	in.pred = 0;
 	if (in.have && (KT_INNER(kt) || (mcu != 0 && !(ri > 0 && mcu % ri == 0)))) {
-		in.pred = fc[(size_t)(blk - (int)KT_BACK(kt)) * 64];
+		in.pred = (int)acdc[blk - (int)KT_BACK(kt)] >> 16;
 	}
 	const int nchunk = min(256, nblk - first) * 8;
 	const int4 *src = reinterpret_cast<const int4 *>(fc + (size_t)first * 64);
@@ -725,7 +803,7 @@ __global__ __launch_bounds__(256) void k_enc_pack(const EncArgs a)
 	__shared__ unsigned scratch[4];
 	__shared__ __align__(16) uint32_t win[WIN_WORDS + 4];      // + sink
 	__shared__ uint32_t stage[256 * ST_STRIDE];
-	__shared__ __align__(8) uint8_t nzmap[256 * 8];
+	__shared__ unsigned long long nzmap[256];
 	__shared__ uint32_t bstart[256], binfo[256], hist[64];
 	__shared__ int bpred[256];
 	__shared__ uint8_t owner[256];
@@ -763,8 +841,8 @@ __global__ __launch_bounds__(256) void k_enc_pack(const EncArgs a)
 			row[1] = (uint32_t)v.y;
 			row[2] = (uint32_t)v.z;
 			row[3] = (uint32_t)v.w;
-			nzmap[ch] = (uint8_t)(nz_pair(v.x) | (nz_pair(v.y) << 2) | (nz_pair(v.z) << 4) | (nz_pair(v.w) << 6));
 		}
+		nzmap[tid] = in.nz;
 		const uint32_t r0 = __builtin_amdgcn_readfirstlane(in.r0), r1 = __builtin_amdgcn_readfirstlane(in.r1);
 		const unsigned mylen = in.mylen, mypad = in.mypad;
 		const int pred = in.pred;
@@ -783,7 +861,7 @@ __global__ __launch_bounds__(256) void k_enc_pack(const EncArgs a)
 		bstart[tid] = r0 + block_excl(mylen, scratch, &total);            // barriers inside: LDS contents visible after
 		// ---- blocks change hands so that the blocks of a wave have similar numbers of nonzero coefficients
 		// (the wave walks as long as its busiest lane): counting sort by that number, busiest first
-		const int bin = 63 - __popcll(reinterpret_cast<const unsigned long long *>(nzmap)[tid] & ~1ull);
+		const int bin = 63 - __popcll(nzmap[tid] & ~1ull);
 		const unsigned rank = atomicAdd(&hist[bin], 1u);
 		__syncthreads();
 		{
@@ -803,7 +881,7 @@ __global__ __launch_bounds__(256) void k_enc_pack(const EncArgs a)
 		const unsigned plen = inf & 0xffffu, ppad = (inf >> 16) & 15u;
 		const bool phave = (inf >> 22) & 1u;
 		const int16_t *mine = reinterpret_cast<const int16_t *>(stage + lb * ST_STRIDE);
-		const unsigned long long nzac = reinterpret_cast<const unsigned long long *>(nzmap)[lb] & ~1ull;
+		const unsigned long long nzac = nzmap[lb] & ~1ull;
 		const int diff = phave ? (int)mine[0] - bpred[lb] : 0;
 		const uint32_t *cd = codes[0 * 2 + ((inf >> 20) & 1u)];
 		const uint32_t *ca = codes[1 * 2 + ((inf >> 21) & 1u)];
@@ -905,6 +983,8 @@ __device__ __forceinline__ unsigned markers_in(const uint32_t *eb, int n, uint32
 	return c;
 }
 
+// The stream of a frame is sized for the worst case but mostly a tenth of that long, and how long is known on
+// the device only: a fixed number of workgroups per frame take the chunks in turn.
 __global__ __launch_bounds__(256) void k_enc_ffcount(const EncArgs a)
 {
 	__shared__ unsigned scratch[4];
@@ -912,26 +992,25 @@ __global__ __launch_bounds__(256) void k_enc_ffcount(const EncArgs a)
 	const int f = blockIdx.y;
 	const JhEncState st = w.state[f];
 	const uint32_t nbytes = (st.status & JH_EST_OVERFLOW) ? 0u : st.us_bytes;
-	const uint32_t base = blockIdx.x * FF_CHUNK + threadIdx.x * 16;
-	if (blockIdx.x * (uint32_t)FF_CHUNK >= nbytes) {
-		return;
-	}
-	unsigned cnt = 0;
-	if (base < nbytes) {
-		const uint4 v = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(w.us) + (size_t)f * w.us_stride + base);
-		const unsigned ws[4] = {v.x, v.y, v.z, v.w};
+	for (uint32_t chunk = blockIdx.x; chunk * (uint32_t)FF_CHUNK < nbytes; chunk += gridDim.x) {
+		const uint32_t base = chunk * FF_CHUNK + threadIdx.x * 16;
+		unsigned cnt = 0;
+		if (base < nbytes) {
+			const uint4 v = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(w.us) + (size_t)f * w.us_stride + base);
+			const unsigned ws[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-		for (int i = 0; i < 16; ++i) {
-			const unsigned byte = (ws[i >> 2] >> (8 * (i & 3))) & 0xffu;
-			cnt += (base + i < nbytes && byte == 0xffu) ? 1u : 0u;
+			for (int i = 0; i < 16; ++i) {
+				const unsigned byte = (ws[i >> 2] >> (8 * (i & 3))) & 0xffu;
+				cnt += (base + i < nbytes && byte == 0xffu) ? 1u : 0u;
+			}
+			if (w.restart_interval > 0) {
+				cnt += 2u * markers_in(w.ivl_eb + (size_t)f * w.nivl, w.nivl - 1, base, base + 16, nullptr);
+			}
 		}
-		if (w.restart_interval > 0) {
-			cnt += 2u * markers_in(w.ivl_eb + (size_t)f * w.nivl, w.nivl - 1, base, base + 16, nullptr);
+		const unsigned total = block_sum(cnt, scratch);
+		if (threadIdx.x == 0) {
+			w.chunk_ff[(size_t)f * w.nchunk + chunk] = total;
 		}
-	}
-	const unsigned total = block_sum(cnt, scratch);
-	if (threadIdx.x == 0) {
-		w.chunk_ff[(size_t)f * w.nchunk + blockIdx.x] = total;
 	}
 }
 
@@ -968,9 +1047,14 @@ __global__ __launch_bounds__(256) void k_enc_ff_scan(const EncArgs a)
 	}
 }
 
+// A chunk's output is put together in LDS (at the byte phase its place in the output has) and stored as whole
+// dwords, the ragged ends byte by byte.  Worst case per chunk: every byte 0xFF and a restart marker in front of
+// every byte.
+#define STUFF_LDS (FF_CHUNK * 4 + 16)
 __global__ __launch_bounds__(256) void k_enc_stuff(const EncArgs a)
 {
 	__shared__ unsigned scratch[4];
+	__shared__ __align__(16) uint8_t obuf[STUFF_LDS];
 	const JhEncodeWork &w = a.w;
 	const int f = blockIdx.y;
 	const JhEncState st = w.state[f];
@@ -978,58 +1062,78 @@ __global__ __launch_bounds__(256) void k_enc_stuff(const EncArgs a)
 		return;
 	}
 	const uint32_t nbytes = st.us_bytes;
-	if (blockIdx.x * (uint32_t)FF_CHUNK >= nbytes) {
-		return;
-	}
-	const uint32_t base = blockIdx.x * FF_CHUNK + threadIdx.x * 16;
-	unsigned bytes[16];
-	unsigned cnt = 0;
 	const uint32_t *eb = w.ivl_eb + (size_t)f * w.nivl;
 	const int nmark = w.restart_interval > 0 ? w.nivl - 1 : 0;
-	int kb = 0;                                                   // next restart marker
-	if (base < nbytes) {
-		const uint4 v = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(w.us) + (size_t)f * w.us_stride + base);
-		const unsigned ws[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-		for (int i = 0; i < 16; ++i) {
-			bytes[i] = (ws[i >> 2] >> (8 * (i & 3))) & 0xffu;
-			cnt += (base + i < nbytes && bytes[i] == 0xffu) ? 1u : 0u;
-		}
-		if (nmark > 0) {
-			cnt += 2u * markers_in(eb, nmark, base, base + 16, &kb);
-		}
-	}
-	unsigned total;
-	unsigned before = w.chunk_ff[(size_t)f * w.nchunk + blockIdx.x] + block_excl(cnt, scratch, &total);
-	if (base >= nbytes) {
-		return;
-	}
 	uint8_t *out = w.out + (size_t)f * w.out_stride + w.hdr_len[f];
-	uint32_t o = base + before;                            // write_ecs_byte (io.c:277-290)
+	for (uint32_t chunk = blockIdx.x; chunk * (uint32_t)FF_CHUNK < nbytes; chunk += gridDim.x) {
+		const uint32_t cbase = chunk * FF_CHUNK, base = cbase + threadIdx.x * 16;
+		unsigned bytes[16];
+		unsigned cnt = 0;
+		int kb = 0;                                                   // next restart marker
+		if (base < nbytes) {
+			const uint4 v = *reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(w.us) + (size_t)f * w.us_stride + base);
+			const unsigned ws[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-	for (int i = 0; i < 16; ++i) {
-		if (base + i < nbytes) {
-			if (kb < nmark && eb[kb] == base + i) {
-				out[o++] = 0xff;                                   // RSTn in front of the interval's first byte
-				out[o++] = (uint8_t)(0xd0 + (kb & 7));
-				++kb;
+			for (int i = 0; i < 16; ++i) {
+				bytes[i] = (ws[i >> 2] >> (8 * (i & 3))) & 0xffu;
+				cnt += (base + i < nbytes && bytes[i] == 0xffu) ? 1u : 0u;
 			}
-			out[o++] = (uint8_t)bytes[i];
-			if (bytes[i] == 0xffu) {
-				out[o++] = 0x00;
+			if (nmark > 0) {
+				cnt += 2u * markers_in(eb, nmark, base, base + 16, &kb);
 			}
 		}
+		unsigned total;
+		const unsigned within = block_excl(cnt, scratch, &total);       // barriers inside: obuf is free again
+		const uint32_t first = cbase + w.chunk_ff[(size_t)f * w.nchunk + chunk];   // where the chunk's output starts
+		const uint32_t phase = (uint32_t)(reinterpret_cast<uintptr_t>(out + first) & 3u);
+		if (base < nbytes) {
+			uint32_t o = phase + threadIdx.x * 16 + within;        // write_ecs_byte (io.c:277-290)
+#pragma unroll
+			for (int i = 0; i < 16; ++i) {
+				if (base + i < nbytes) {
+					if (kb < nmark && eb[kb] == base + i) {
+						obuf[o++] = 0xff;                              // RSTn in front of the interval's first byte
+						obuf[o++] = (uint8_t)(0xd0 + (kb & 7));
+						++kb;
+					}
+					obuf[o++] = (uint8_t)bytes[i];
+					if (bytes[i] == 0xffu) {
+						obuf[o++] = 0x00;
+					}
+				}
+			}
+		}
+		__syncthreads();
+		const uint32_t nout = min((uint32_t)FF_CHUNK, nbytes - cbase) + total;
+		uint8_t *dst = out + first - phase;                        // dword aligned
+		const uint32_t end = phase + nout;
+		for (uint32_t x = threadIdx.x * 4; x < end; x += 1024) {
+			if (x >= phase && x + 4 <= end) {
+				*reinterpret_cast<uint32_t *>(dst + x) = *reinterpret_cast<const uint32_t *>(obuf + x);
+			} else {
+				for (uint32_t i = x < phase ? phase : x; i < x + 4 && i < end; ++i) {
+					dst[i] = obuf[i];
+				}
+			}
+		}
+		__syncthreads();
 	}
 }
 
-int jh_launch_enc_entropy(const JhEncodeWork &w, const JhGeom &g, hipStream_t s, const JhTimerHook *th)
+int jh_launch_enc_entropy(const JhEncodeWork &w, const JhGeom &g, hipStream_t s, const JhTimerHook *th, bool acbits_ready)
 {
 	EncArgs a;
 	a.w = w;
 	a.g = g;
-	JH_T_BEGIN(th, "k_enc_bitlen", s);
-	hipLaunchKernelGGL(k_enc_bitlen, dim3(w.nwg, w.nframes), dim3(256), 0, s, a);
-	JH_T_END(th, s);
+	if (acbits_ready) {
+		JH_T_BEGIN(th, "k_enc_dcbits", s);
+		hipLaunchKernelGGL(k_enc_dcbits, dim3(w.nwg, w.nframes), dim3(256), 0, s, a);
+		JH_T_END(th, s);
+	} else {
+		JH_T_BEGIN(th, "k_enc_bitlen", s);
+		hipLaunchKernelGGL(k_enc_bitlen, dim3(w.nwg, w.nframes), dim3(256), 0, s, a);
+		JH_T_END(th, s);
+	}
 	JH_T_BEGIN(th, "k_enc_wg_scan", s);
 	hipLaunchKernelGGL(k_enc_wg_scan, dim3(w.nframes), dim3(256), 0, s, a);
 	JH_T_END(th, s);
@@ -1044,14 +1148,17 @@ int jh_launch_enc_entropy(const JhEncodeWork &w, const JhGeom &g, hipStream_t s,
 	const int pack_wgs = w.nwg >= 64 ? (w.nwg + 3) / 4 : w.nwg;
 	hipLaunchKernelGGL(k_enc_pack, dim3(pack_wgs, w.nframes), dim3(256), 0, s, a);
 	JH_T_END(th, s);
+	// chunks per frame are a capacity (the stream's real length is on the device): some workgroups per frame
+	// walk them, about 8192 in all
+	const int ff_wgs = min(w.nchunk, max(32, 8192 / w.nframes));
 	JH_T_BEGIN(th, "k_enc_ffcount", s);
-	hipLaunchKernelGGL(k_enc_ffcount, dim3(w.nchunk, w.nframes), dim3(256), 0, s, a);
+	hipLaunchKernelGGL(k_enc_ffcount, dim3(ff_wgs, w.nframes), dim3(256), 0, s, a);
 	JH_T_END(th, s);
 	JH_T_BEGIN(th, "k_enc_ff_scan", s);
 	hipLaunchKernelGGL(k_enc_ff_scan, dim3(w.nframes), dim3(256), 0, s, a);
 	JH_T_END(th, s);
 	JH_T_BEGIN(th, "k_enc_stuff", s);
-	hipLaunchKernelGGL(k_enc_stuff, dim3(w.nchunk, w.nframes), dim3(256), 0, s, a);
+	hipLaunchKernelGGL(k_enc_stuff, dim3(ff_wgs, w.nframes), dim3(256), 0, s, a);
 	JH_T_END(th, s);
 	return hipGetLastError() == hipSuccess ? 0 : -1;
 }

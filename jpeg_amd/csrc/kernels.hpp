@@ -98,8 +98,20 @@ int jh_launch_huff_decode(const JhDecodeWork &w, const JhGeom &g, hipStream_t s,
 
 int jh_launch_decode_pixels(const JhGeom &g, int nframes, const int16_t *coefs, const JhQuant *quant,
                             void *out, size_t frame_stride, hipStream_t stream);
+// What the entropy encoder wants to know about a block besides its coefficients: the map of its nonzero
+// coefficients (bit k: coefficient k in zig-zag order) and one word (`acdc`) with the bits its AC symbols will
+// take in the low half (write_ac, coeffs.c:164-194, EOB / ZRL included; JH_ACBITS_NOCODE: a symbol has no code,
+// value_to_vlc == -1) and the quantised DC coefficient, before prediction, in the high half.  Written by the
+// pixel kernel while the quantised block is still in LDS (default tables: the frame's codes are known then), or
+// by k_enc_bitlen from the coefficients (optimised tables, coefficients handed in by the caller: AC bits 0);
+// read by k_enc_dcbits (DC symbol + sums) and by k_enc_pack instead of a second look at the coefficients.
+#define JH_ACBITS_NOCODE 0xffffu
+
+// codes: NULL, or the frames' codes ([frame][4]): the kernel then also fills nzmap[] / acdc[] ([frame][nblk]) with
+// the AC code sizes of codes[frame * 4 + 2 + Ta]
 int jh_launch_encode_pixels(const JhGeom &g, int nframes, const void *in, size_t frame_stride,
-                            const JhQuant *quant_raster, int16_t *coefs, hipStream_t stream);
+                            const JhQuant *quant_raster, int16_t *coefs, unsigned long long *nzmap, uint32_t *acdc,
+                            const JhHuffEnc *codes, hipStream_t stream);
 
 int jh_launch_selftest_divide(unsigned long long *d_out, int per, unsigned seed, hipStream_t stream);
 
@@ -131,6 +143,8 @@ struct JhEncodeWork {
 	JhHuffEnc *codes;             // [frame][Tc*2+Th]: DC0, DC1, AC0, AC1 (table ids 0/1 only, as the encoder uses)
 	uint32_t *hist;               // [frame][4][257] symbol counts (optimised tables)
 	uint16_t *bitlen;             // [frame][nblk]
+	unsigned long long *nzmap;    // [frame][nblk] nonzero maps
+	uint32_t *acdc;               // [frame][nblk] AC bits | DC coefficient << 16
 	uint32_t *wg_bits;            // [frame][nwg] per-workgroup sums, then exclusive bases
 	uint32_t *us;                 // unstuffed streams, frame stride us_stride bytes
 	size_t us_stride;
@@ -157,4 +171,6 @@ struct JhEncodeWork {
 int jh_launch_enc_histogram(const JhEncodeWork &w, const JhGeom &g, hipStream_t s, const JhTimerHook *th);
 int jh_launch_enc_adapt(const JhEncodeWork &w, const JhGeom &g, hipStream_t s, const JhTimerHook *th);
 int jh_launch_enc_headers(const JhEncodeWork &w, const JhGeom &g, hipStream_t s);
-int jh_launch_enc_entropy(const JhEncodeWork &w, const JhGeom &g, hipStream_t s, const JhTimerHook *th);
+// acbits_ready: the pixel kernel has filled w.nzmap / w.acdc with the codes in w.codes: the bit lengths then need
+// the DC symbols only (k_enc_dcbits); otherwise k_enc_bitlen walks the coefficients and fills both arrays
+int jh_launch_enc_entropy(const JhEncodeWork &w, const JhGeom &g, hipStream_t s, const JhTimerHook *th, bool acbits_ready);

@@ -139,6 +139,7 @@ struct TileLayout {
 	int kpitch[JH_MAX_MCU_BLOCKS];
 	int kmst[JH_MAX_MCU_BLOCKS];        // 8 * H of the block's component: column step per MCU
 	int ktq[JH_MAX_MCU_BLOCKS];         // quantisation table of the block's component
+	int kta[JH_MAX_MCU_BLOCKS];         // its AC table id, 0 / 1 (encoder)
 	int sx_magic[JH_MAX_COMP], sy_magic[JH_MAX_COMP];   // 65536 / step + 1: c = (p * magic) >> 16
 	int lds_floats;
 };
@@ -169,6 +170,7 @@ static void make_layout(const JhGeom &g, TileLayout *t)
 		t->kpitch[k] = t->pitch[c];
 		t->kmst[k] = 8 * g.H[c];
 		t->ktq[k] = g.Tq[c] & 3;
+		t->kta[k] = g.Ta[c] & 1;
 	}
 }
 
@@ -181,6 +183,7 @@ struct BlockTask {
 // per-k tables staged in LDS (indexed per lane)
 struct KTab {
 	int koff[JH_MAX_MCU_BLOCKS], kpitch[JH_MAX_MCU_BLOCKS], kmst[JH_MAX_MCU_BLOCKS], ktq[JH_MAX_MCU_BLOCKS];
+	int kta[JH_MAX_MCU_BLOCKS];         // AC table id (0 / 1) of the block's component
 	uint32_t zig[8][2];                 // 8 raster indices (one byte each) per zig-zag octet
 	uint8_t invz[64];                   // raster index -> zig-zag position
 };
@@ -192,6 +195,7 @@ __device__ __forceinline__ void stage_ktab(KTab &kt, const TileLayout &L, int B,
 		kt.kpitch[tid] = L.kpitch[tid];
 		kt.kmst[tid] = L.kmst[tid];
 		kt.ktq[tid] = L.ktq[tid];
+		kt.kta[tid] = L.kta[tid];
 	}
 	if (tid >= 64 && tid < 72) {
 		const int j = tid - 64;
@@ -505,6 +509,9 @@ struct EncPixArgs {
 	size_t frame_stride;
 	const JhQuant *quant;      // [frame] RASTER order here (divisors are applied in raster order)
 	int16_t *coefs;            // [frame][nblk][64] zig-zag
+	unsigned long long *nzmap; // [frame][nblk] (with codes)
+	uint32_t *acdc;            // [frame][nblk] (with codes)
+	const JhHuffEnc *codes;    // [frame][4] the codes in force for the frame, or NULL
 	TileLayout L;
 	JhGeom g;
 };
@@ -555,14 +562,38 @@ __device__ __forceinline__ void load4(const uint8_t *inf, int X, int Y, int sb, 
 	}
 }
 
+// bit 0: the low int16 of d is nonzero, bit 1: the high one
+__device__ __forceinline__ unsigned nz_pair16(int d)
+{
+	typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+	const us2 one = {1, 1};
+	const unsigned x = __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(us2, d), one));
+	return (x | (x >> 15)) & 3u;
+}
+
+// Stage 5 of the encode kernel (bits of every block's AC symbols) works in the part of the tile's LDS that
+// lies behind the blocks' int16 lines and is free once the float planes are dead:
+//   nzm    the blocks' nonzero maps, one byte per octet
+//   pbits  AC bits of the two halves of a block
+//   actab  size + category of every AC symbol per table id (0: never looked up, 0x4000: no code)
+//   acfix  sizes of EOB / ZRL per table id
+struct Stage5 {
+	unsigned long long nzm[128];
+	unsigned pbits[2][128];
+	uint16_t actab[2][256];
+	uint16_t acfix[2][2];
+};
+#define STAGE5_OFF (TILE_BLOCKS * 128)             // bytes: behind the lines of a full tile
+
 // NF = 1: one plane, no sub-sampling.  NF = 3: luma at full resolution, both chroma planes
 // down-sampled SX x SY (what read_image() sets up: luma H x V, chroma 1 x 1; encoder.c:109-146).
 template <int NF, int SX, int SY>
 __global__ __launch_bounds__(256) void k_encode_pixels(const EncPixArgs a)
 {
 	extern __shared__ __align__(16) float tile[];
-	__shared__ float2 sqf[4][64];     // x: divisor, y: its refined reciprocal (see quantise below)
+	__shared__ float2 sqf[4][64];     // x: divisor, y: its refined reciprocal (see quant_divide)
 	__shared__ KTab kt;
+	Stage5 &s5 = *reinterpret_cast<Stage5 *>(reinterpret_cast<char *>(tile) + STAGE5_OFF);
 
 	const JhGeom &g = a.g;
 	const TileLayout &L = a.L;
@@ -731,24 +762,102 @@ __global__ __launch_bounds__(256) void k_encode_pixels(const EncPixArgs a)
 		for (int it = 0; it < TILE_ROUNDS; ++it) {
 			const int t = tid + it * 256;
 			if (t < ntask) {
-				dst[t] = stg[t];
+				const int4 v = stg[t];
+				dst[t] = v;
+				if (a.codes) {
+					reinterpret_cast<uint8_t *>(s5.nzm)[t] = (uint8_t)(nz_pair16(v.x) | (nz_pair16(v.y) << 2) |
+					                                                 (nz_pair16(v.z) << 4) | (nz_pair16(v.w) << 6));
+				}
 			}
 		}
+	}
+	if (!a.codes) {
+		return;
+	}
+	for (int i = tid; i < 2 * 256; i += 256) {
+		const int th = i >> 8, sym = i & 255, cat = sym & 15;
+		const unsigned size = a.codes[(size_t)f * 4 + 2 + th].code[sym] & 0xffu;
+		s5.actab[th][sym] = (uint16_t)(cat == 0 ? 0u : (size ? size + (unsigned)cat : 0x4000u));
+		if (sym == 0x00) {
+			s5.acfix[th][0] = (uint16_t)(size ? size : 0x4000u);
+		}
+		if (sym == 0xf0) {
+			s5.acfix[th][1] = (uint16_t)(size ? size : 0x4000u);
+		}
+	}
+	__syncthreads();
+
+	// ---- 5: (block, half): what write_ac() will spend on the block (coeffs.c:164-194, Figure F.2), walked over
+	// the nonzero coefficients only (the zero run is the distance to the previous one).  Two lanes per block,
+	// coefficients 1..31 and 32..63, the halves in different waves (the first half holds most of the work);
+	// the next coefficient is fetched while the current symbol is priced.
+	static_assert(TILE_BLOCKS <= 128, "stage 5 maps a tile's blocks to 128 lanes");
+	const int nb = ntask >> 3;
+	{
+		const int h = tid >> 7, b = tid & 127;
+		if (b < nb) {
+			const int mcu = B == 1 ? b : (int)(__umul24((unsigned)b, L.b_magic16) >> 16);
+			const int k = b - (int)__umul24((unsigned)mcu, (unsigned)B);
+			const int ta = kt.kta[k];
+			const uint16_t *T = s5.actab[ta];
+			const unsigned eob = s5.acfix[ta][0], zrl = s5.acfix[ta][1];
+			const int16_t *line = reinterpret_cast<const int16_t *>(tile) + b * 64 + h * 32;
+			const unsigned long long map = s5.nzm[b];
+			const unsigned lo = (unsigned)map & ~1u, hi = (unsigned)(map >> 32);
+			unsigned m = h ? hi : lo;
+			// position (inside this half) of the nonzero coefficient before the first of this half; DC counts as one
+			int prev = h ? (31 - __builtin_clz(lo | 1u)) - 32 : 0;
+			unsigned bits = 0, tprev = 0;
+			int z = m ? __builtin_ctz(m) : 0;
+			int c = line[z];
+			while (m) {
+				m &= m - 1;
+				const int zn = m ? __builtin_ctz(m) : 0;
+				const int cn = line[zn];
+				const int run = z - prev - 1;
+				prev = z;
+				const int cat = __builtin_amdgcn_frexp_expf((float)c);  // bits of |c| (encode_cat, coeffs.c:56-74)
+				bits += tprev + (unsigned)(run >> 4) * zrl;
+				tprev = T[((run & 15) << 4) | cat];
+				z = zn;
+				c = cn;
+			}
+			bits += tprev;
+			if (h && !(hi >> 31)) {
+				bits += eob;
+			}
+			s5.pbits[h][b] = bits;
+		}
+	}
+	__syncthreads();
+	if (tid < nb) {
+		const unsigned bits = s5.pbits[0][tid] + s5.pbits[1][tid];
+		const size_t blk = (size_t)f * g.nblk + (size_t)(my * g.m_x + mx0) * B + tid;
+		const unsigned dc = (unsigned)(uint16_t)reinterpret_cast<const int16_t *>(tile)[tid * 64];
+		a.nzmap[blk] = s5.nzm[tid];
+		a.acdc[blk] = (bits >= 0x4000u ? JH_ACBITS_NOCODE : bits) | (dc << 16);
 	}
 }
 
 int jh_launch_encode_pixels(const JhGeom &g, int nframes, const void *in, size_t frame_stride,
-                            const JhQuant *quant_raster, int16_t *coefs, hipStream_t stream)
+                            const JhQuant *quant_raster, int16_t *coefs, unsigned long long *nzmap, uint32_t *acdc,
+                            const JhHuffEnc *codes, hipStream_t stream)
 {
 	EncPixArgs a;
 	a.in = (const uint8_t *)in;
 	a.frame_stride = frame_stride;
 	a.quant = quant_raster;
 	a.coefs = coefs;
+	a.nzmap = nzmap;
+	a.acdc = acdc;
+	a.codes = nzmap && acdc ? codes : nullptr;
 	make_layout(g, &a.L);
 	a.g = g;
 	dim3 grid((g.m_x + a.L.G - 1) / a.L.G, g.m_y, nframes);
-	const size_t lds = (size_t)a.L.lds_floats * sizeof(float);
+	size_t lds = (size_t)a.L.lds_floats * sizeof(float);
+	if (a.codes && lds < STAGE5_OFF + sizeof(Stage5)) {
+		lds = STAGE5_OFF + sizeof(Stage5);                 // small tiles: room for stage 5 behind the lines
+	}
 	if (g.Nf == 1) {
 		hipLaunchKernelGGL((k_encode_pixels<1, 1, 1>), grid, dim3(256), lds, stream, a);
 	} else if (g.Nf == 3 && g.step_x[0] == 1 && g.step_y[0] == 1 && g.step_x[1] == g.max_H && g.step_y[1] == g.max_V &&
