@@ -591,7 +591,8 @@ template <int NF, int SX, int SY>
 __global__ __launch_bounds__(256) void k_encode_pixels(const EncPixArgs a)
 {
 	extern __shared__ __align__(16) float tile[];
-	__shared__ float2 sqf[4][64];     // x: divisor, y: its refined reciprocal (see quant_divide)
+	__shared__ float2 sqf[2][64];     // x: divisor, y: its refined reciprocal (see quant_divide); the encoder's frames
+	                                  // use tables 0 / 1 only (encoder.c:133-135)
 	__shared__ KTab kt;
 	Stage5 &s5 = *reinterpret_cast<Stage5 *>(reinterpret_cast<char *>(tile) + STAGE5_OFF);
 
@@ -607,7 +608,7 @@ __global__ __launch_bounds__(256) void k_encode_pixels(const EncPixArgs a)
 	const float shiftf = (float)shift;
 	const uint8_t *inf = a.in + (size_t)f * a.frame_stride;
 
-	for (int i = tid; i < 4 * 64; i += 256) {
+	for (int i = tid; i < 2 * 64; i += 256) {
 		const float d = (float)a.quant[f].q[i >> 6][i & 63];
 		sqf[i >> 6][i & 63] = make_float2(d, quant_reciprocal(d));
 	}
@@ -723,7 +724,7 @@ __global__ __launch_bounds__(256) void k_encode_pixels(const EncPixArgs a)
 			if (t < ntask) {
 				const int pitch = bts[it].pitch;
 				const float *p = tile + bts[it].addr + sub;
-				const float2 *q = &sqf[bts[it].tq][sub];
+				const float2 *q = &sqf[bts[it].tq & 1][sub];
 				float in[8], o[8];
 #pragma unroll
 				for (int y = 0; y < 8; ++y) {
