@@ -215,6 +215,7 @@ struct jpeg_hip_decoder {
 	std::vector<int> parse_err;
 	std::vector<size_t> ecs_len;
 	std::vector<size_t> file_off, file_len;   // the frames inside h_stage (valid until the next prepare)
+	std::vector<size_t> spliced;              // bytes sync() cut out of a frame behind stray markers (see there)
 	// device
 	uint8_t *d_raw = nullptr;
 	uint8_t *h_stage = nullptr;       // pinned staging for the codestreams, kept between prepare() calls
@@ -317,7 +318,13 @@ struct ScanDesc {
 // SOI .. EOI of one frame: headers, and the list of scans.  Tables may be redefined between scans
 // (decoder.c:581-591 runs whenever a DHT comes); quantisation tables count as they stand at EOI,
 // where the reference dequantises (decoder.c:456-470).
-static int parse_frame(const uint8_t *p, size_t n, JhHeader *h, std::vector<ScanDesc> *scans, bool tolerant)
+// cut (optional): a scan of some components that ends on a marker behind which only skippable segments and then
+// RSTn follow goes on at that RSTn in the reference (decoder.c:622-633, see jpeg_hip_decoder_sync).  Then the
+// bytes [cut[0], cut[1]) are the ones to take out and PARSE_SPLICE is returned: the caller parses the file
+// without them.
+enum { PARSE_SPLICE = 0x7fff0001 };
+
+static int parse_frame(const uint8_t *p, size_t n, JhHeader *h, std::vector<ScanDesc> *scans, bool tolerant, size_t *cut = nullptr)
 {
 	scans->clear();
 	int err = jh_parse_headers(p, n, h, tolerant);
@@ -374,6 +381,12 @@ static int parse_frame(const uint8_t *p, size_t n, JhHeader *h, std::vector<Scan
 		if (end >= n) {
 			return RET_FAILURE_FILE_IO;                    // no marker after the data (io.c:197)
 		}
+		size_t rst = 0;
+		if (cut && p[end + 1] != 0xd9 && jh_walk_to_restart(p, n, end, tolerant, &rst) == RET_SUCCESS && rst > end) {
+			cut[0] = end;
+			cut[1] = rst;
+			return PARSE_SPLICE;
+		}
 		describe(k, end + 2);
 		bool eoi = false;
 		err = jh_parse_next_scan(p, n, end, h, &eoi);
@@ -407,6 +420,7 @@ static int decoder_prepare(jpeg_hip_decoder *dec, int nframes, const uint8_t *co
 	dec->nframes = 0;                                      // not prepared until everything below has succeeded
 	dec->parse_err.assign(nframes, 0);
 	dec->ecs_len.assign(nframes, 0);
+	dec->spliced.assign(nframes, 0);
 
 	auto T0 = std::chrono::steady_clock::now();
 	auto lap = [&](const char *what) {
@@ -421,7 +435,6 @@ static int decoder_prepare(jpeg_hip_decoder *dec, int nframes, const uint8_t *co
 	std::vector<JhQuant> quant(nframes);
 	std::vector<size_t> &file_off = dec->file_off;
 	file_off.assign(nframes, 0);
-	dec->file_len.assign(jpg_len, jpg_len + nframes);
 	std::vector<ScanDesc> pass_comp;                       // the batch's scan structure (from the first good frame)
 	bool have_geom = false;
 	size_t raw_off = 0;
@@ -465,6 +478,7 @@ static int decoder_prepare(jpeg_hip_decoder *dec, int nframes, const uint8_t *co
 			}
 		}
 	}
+	dec->file_len.assign(jpg_len, jpg_len + nframes);      // after the parsing: it may hand back a shorter file
 	lap("parse");
 	if (!have_geom) {
 		// nothing decodable: report the first parse error
@@ -750,8 +764,26 @@ extern "C" int jpeg_hip_decoder_prepare(jpeg_hip_decoder *dec, int nframes,
 	if (!dec || nframes <= 0 || !jpg || !jpg_len) {
 		return RET_FAILURE_LOGIC_ERROR;
 	}
-	return decoder_prepare(dec, nframes, jpg, jpg_len, [&](int f, JhHeader *h, std::vector<ScanDesc> *sc) {
-		return parse_frame(jpg[f], jpg_len[f], h, sc, dec->tolerant);
+	std::vector<const uint8_t *> file(jpg, jpg + nframes);
+	std::vector<size_t> file_len(jpg_len, jpg_len + nframes);
+	std::vector<std::vector<uint8_t>> patched(nframes);    // damaged files with several scans, see parse_frame()
+	return decoder_prepare(dec, nframes, file.data(), file_len.data(), [&](int f, JhHeader *h, std::vector<ScanDesc> *sc) {
+		int err = RET_FAILURE_FILE_UNSUPPORTED;
+		for (int tries = 0; tries < 64; ++tries) {
+			size_t cut[2] = {0, 0};
+			err = parse_frame(file[f], file_len[f], h, sc, dec->tolerant, cut);
+			if (err != PARSE_SPLICE) {
+				return err;
+			}
+			std::vector<uint8_t> &v = patched[f];
+			if (v.empty()) {
+				v.assign(file[f], file[f] + file_len[f]);
+			}
+			v.erase(v.begin() + cut[0], v.begin() + cut[1]);
+			file[f] = v.data();
+			file_len[f] = v.size();
+		}
+		return err == PARSE_SPLICE ? RET_FAILURE_FILE_UNSUPPORTED : err;
 	});
 }
 
@@ -873,7 +905,41 @@ extern "C" int jpeg_hip_decoder_sync(jpeg_hip_decoder *dec, int *frame_status)
 			ps.work.seg_start = ps.d_seg;
 			ps.work.drop = ps.d_drop;
 		}
-		if (!again || attempt > 0) {
+		// A marker inside the data of a scan that is neither RSTn nor EOI ends read_ecs() (io.c:257-268);
+		// parse_format() goes on from it (decoder.c:487-657), skips what it can skip (TEM, APPn, COM, DAC, DRI
+		// segments by their length, bytes between markers) and, when it arrives at an RSTn, decodes on from
+		// there (decoder.c:622-633) with the MCU counter where it stood.  For the decoder that is the stream with
+		// the skipped bytes cut out: done here on the host copy of the frame, and the batch runs once more.
+		if (!again && dec->pass.size() == 1 && dec->pass[0].comp == -1 && !dec->coefs_only && dec->h_stage) {
+			DecPass &ps = dec->pass[0];
+			bool cut = false;
+			for (int f = 0; f < dec->nframes; ++f) {
+				const JhDecState &ds = ps.state[f];
+				JhDecFrame &fr = ps.frames[f];
+				if (dec->parse_err[f] || (ds.status & JH_ST_SEG_OVERFLOW) || ds.term_pos + 1 >= fr.raw_end || ds.term_marker == 0xd9) {
+					continue;
+				}
+				uint8_t *file = dec->h_stage + dec->file_off[f];
+				const size_t len = dec->file_len[f], rel = ds.term_pos - dec->file_off[f];
+				size_t rst = 0;
+				if (rel >= len || jh_walk_to_restart(file, len, rel, dec->tolerant, &rst) != RET_SUCCESS || rst <= rel) {
+					continue;                                  // EOI, or something that ends the decoding: settled below
+				}
+				const size_t removed = rst - rel;
+				memmove(file + rel, file + rst, len - rst);
+				memset(file + len - removed, 0, removed);
+				HIPCHK(hipMemcpy(dec->d_raw + dec->file_off[f] + rel, file + rel, len - rel, hipMemcpyHostToDevice));
+				dec->file_len[f] = len - removed;
+				dec->spliced[f] += removed;
+				fr.raw_end -= (uint32_t)removed;
+				cut = true;
+			}
+			if (cut) {
+				HIPCHK(hipMemcpy(ps.d_frames, ps.frames.data(), dec->nframes * sizeof(JhDecFrame), hipMemcpyHostToDevice));
+				again = true;
+			}
+		}
+		if (!again || attempt >= 64) {
 			break;
 		}
 		const int err = decoder_launch(dec, dec->last_stream);
@@ -889,7 +955,7 @@ extern "C" int jpeg_hip_decoder_sync(jpeg_hip_decoder *dec, int *frame_status)
 		for (size_t pi = 0; pi < dec->pass.size() && !st; ++pi) {
 			const JhDecState &ds = dec->pass[pi].state[f];
 			const JhDecFrame &fr = dec->pass[pi].frames[f];
-			dec->ecs_len[f] += ds.term_pos - fr.raw_begin;
+			dec->ecs_len[f] += ds.term_pos - fr.raw_begin + dec->spliced[f];
 			if (ds.status & JH_ST_SEG_OVERFLOW) {
 				st = RET_FAILURE_FILE_UNSUPPORTED;
 			} else if (ds.term_pos + 1 >= fr.raw_end) {
@@ -898,9 +964,9 @@ extern "C" int jpeg_hip_decoder_sync(jpeg_hip_decoder *dec, int *frame_status)
 				// A scan of all components that ends on something else than EOI.  parse_format() goes on from
 				// that marker (decoder.c:487-657): TEM, APPn, COM, DAC and table segments pass, whatever
 				// lies between markers is skipped (io.c:196-210), EOI ends the image with what was decoded.
-				// The same walk here, on the host copy of the file.  More entropy-coded data behind it (RSTn
-				// after a stray marker, another SOS) is not on the GPU path, and new quantisation tables would
-				// change the image already made.
+				// The same walk here, on the host copy of the file (restart intervals behind such a marker have
+				// been spliced in above).  Another SOS behind it is not on the GPU path, and new quantisation
+				// tables would change the image already made.
 				st = RET_FAILURE_FILE_UNSUPPORTED;
 				JhHeader h0, h1;
 				const uint8_t *file = dec->h_stage + dec->file_off[f];

@@ -608,6 +608,52 @@ int jh_parse_next_scan(const uint8_t *p, size_t n, size_t pos, JhHeader *h, bool
 	return parse_segments(r, h, eoi);
 }
 
+int jh_walk_to_restart(const uint8_t *p, size_t n, size_t pos, bool tolerant, size_t *rst)
+{
+	Reader r = {p, n, pos};
+	*rst = 0;
+	for (;;) {
+		unsigned m;
+		int err = next_marker(r, &m);
+		if (err) {
+			return err;
+		}
+		if (m == 0xffd8 || m == 0xff01) {                      // SOI, TEM
+			continue;
+		}
+		if (m >= 0xffd0 && m <= 0xffd7) {
+			*rst = r.pos - 2;
+			return RET_SUCCESS;
+		}
+		if (m == 0xffd9) {
+			return RET_SUCCESS;
+		}
+		const bool extra = tolerant && (m == 0xffe9 || m == 0xffea || m == 0xffef || m == 0xffdc || (m >= 0xfff0 && m <= 0xfffd));
+		if ((m >= 0xffe0 && m <= 0xffe8) || (m >= 0xffeb && m <= 0xffee) || m == 0xffcc || m == 0xfffe || m == 0xffdd || extra) {
+			if (!r.ok(2)) {
+				return RET_FAILURE_FILE_IO;
+			}
+			const size_t len = ((size_t)p[r.pos] << 8) | p[r.pos + 1];
+			if (m == 0xfffe && len < 2) {
+				return RET_FAILURE_FILE_UNSUPPORTED;
+			}
+			if (m == 0xffdd) {
+				if (!r.ok(4)) {
+					return RET_FAILURE_FILE_IO;                    // read_length + read_word (decoder.c:616-619)
+				}
+				r.pos += 4;                                        // Ri is stored and never used (quirk Q1)
+				continue;
+			}
+			r.pos += len;
+			if (r.pos > n) {
+				return RET_FAILURE_FILE_IO;
+			}
+			continue;
+		}
+		return RET_FAILURE_FILE_UNSUPPORTED;                   // tables, frames, scans, unknown markers: not on this path
+	}
+}
+
 // read_ecs_byte (io.c:247-274): the entropy-coded data ends at the first FF xx with xx not in {00, D0..D7}
 size_t jh_ecs_end(const uint8_t *p, size_t n, size_t pos)
 {

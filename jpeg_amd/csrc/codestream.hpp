@@ -30,6 +30,12 @@ int jh_parse_headers(const uint8_t *p, size_t n, JhHeader *h, bool tolerant = fa
 // Files with several scans (non-interleaved components, decoder.c:593-633): continue behind the entropy-coded
 // data of a scan.  Tables may be redefined on the way; *eoi = true when EOI came instead of another SOS.
 int jh_parse_next_scan(const uint8_t *p, size_t n, size_t pos, JhHeader *h, bool *eoi);
+// parse_format() (decoder.c:487-657) from a marker inside a scan's data that is neither RSTn nor EOI, as far as
+// it only SKIPS things: TEM, APPn, COM, DAC and DRI segments by their length, bytes between markers
+// (read_marker(), io.c:186-220).  *rst = position of the first RSTn it arrives at (the reference decodes on
+// from there, decoder.c:622-633) or 0; RET_SUCCESS with *rst == 0: it arrived at EOI.  Everything else --
+// table or frame segments, another SOS, markers the reference does not know -- is returned as an error.
+int jh_walk_to_restart(const uint8_t *p, size_t n, size_t pos, bool tolerant, size_t *rst);
 size_t jh_ecs_end(const uint8_t *p, size_t n, size_t pos);            // position of the marker that ends the ECS, or n
 
 // Geometry from P/X/Y/components (common.c:156-195, frame.c:16-35).  interleaved = scan holds all

@@ -414,7 +414,6 @@ __global__ __launch_bounds__(WR_THREADS) void k_huff_write(const HuffArgs a)
 	bool act = t < nsub;
 	uint32_t pos = 0, seg = 0, seg_end = 0;
 	int c = 0, z = 0, blk = 0;
-	int limit_blk = 0x7fffffff;                      // blocks from this index on belong to later threads
 	if (act) {
 		const WrEntry e = load_entry(w, fr, t);
 		pos = e.pos;
@@ -431,10 +430,6 @@ __global__ __launch_bounds__(WR_THREADS) void k_huff_write(const HuffArgs a)
 		if (act) {
 			seg_end = min(seg_start[seg + 1] * 8u, total_bits);
 		}
-		if (t + 1 < nsub) {
-			const WrEntry e1 = load_entry(w, fr, t + 1);
-			limit_blk = e1.blk + (e1.z != 0 ? 1 : 0);
-		}
 	}
 	const uint32_t stop = (t + 1) * JH_SUBSEQ_BITS;
 	bool own = z == 0;                               // a thread that enters mid-block does not own that block
@@ -443,6 +438,7 @@ __global__ __launch_bounds__(WR_THREADS) void k_huff_write(const HuffArgs a)
 	int cn = 0;
 	uint4 ent_n = make_uint4(0, 0, 0, 0);
 	uint32_t wi = 0, w0 = 0, w1 = 0, w2 = 0, win = 0, tac = 0, tab = 0, dca = 0;
+	int lastold = 0;                                 // DC predictor that went into the block in progress
 	RegStream::Cursor cur;
 	cur.b = cur.c = cur.d = 0;
 	cur.nq = 4;
@@ -504,6 +500,7 @@ __global__ __launch_bounds__(WR_THREADS) void k_huff_write(const HuffArgs a)
 				int *acc = reinterpret_cast<int *>(reinterpret_cast<char *>(dcs) + dca);
 				const int old = atomicAdd(acc, isdc ? val : 0);     // DC un-prediction (decoder.c:351-355)
 				val += isdc ? old : 0;
+				lastold = isdc ? old : lastold;
 				c = done ? cn : c;
 				tac = done ? ent_n.y : tac;
 				dca = done ? ent_n.z : dca;
@@ -528,14 +525,30 @@ __global__ __launch_bounds__(WR_THREADS) void k_huff_write(const HuffArgs a)
 				cat = (int)(e1 & 15u);
 				const uint32_t npos = pos + (uint32_t)total;
 				if (e1 == 0 || npos > seg_end) {
-					// end of this restart segment (decoder.c:376-381): the MCU in progress is dropped, the
-					// next segment starts with block 0 / DC predictors 0 (decoder.c:369-373).
-					// The blocks of the dropped MCU were stored when they were completed, possibly by other
-					// threads, and the next segment's blocks go to the same places: k_huff_fixup settles
+					// End of this restart segment (decoder.c:376-381): the MCU in progress is not counted, the next
+					// segment starts at its first block with DC predictors 0 (decoder.c:369-373).  What the reference
+					// has stored of that MCU stays until the next segment overwrites it: the blocks it completed
+					// (flushed already), and the block it was reading when the data ran out, once its DC symbol was
+					// in -- with the DC DIFFERENCE, since the prediction is added after read_block() has succeeded
+					// (coeffs.c:222, decoder.c:347-353), and the AC coefficients read so far.
+					// The next segment's blocks go to the same places, stored by other threads: k_huff_fixup settles
 					// the order afterwards.  Recorded by the thread in whose sub-sequence the segment ends.
-					if (c != 0 && pos < stop && seg + 1 < nseg) {
-						w.drop[fr.seg_off + seg + 1] = ((unsigned long long)(uint32_t)(blk - c) << 8) | (unsigned)c;
-						atomicAdd(&w.state[f].ndrop, 1u);
+					const bool partial = z != 0;
+					if (pos < stop && (c != 0 || partial)) {
+						if (seg + 1 < nseg) {
+							w.drop[fr.seg_off + seg + 1] = ((unsigned long long)(uint32_t)(blk - c) << 8) | (unsigned)(c + (partial ? 1 : 0));
+							atomicAdd(&w.state[f].ndrop, 1u);
+						} else {
+							atomicMax(&w.state[f].ntail, (uint32_t)max(blk + (partial ? 1 : 0), 0));
+						}
+					}
+					if (partial) {
+						mybuf[(tid & 7) << 3] -= (int16_t)lastold;     // coefficient 0 sits in chunk (0 + tid) & 7
+						fin = true;
+						fblk = (own && blk >= 0 && blk < nblk) ? blk : -1;
+						if (REMAP && fblk >= 0) {
+							fblk = remap_block(rm, fblk);
+						}
 					}
 					blk -= c;
 					c = 0;
@@ -544,10 +557,6 @@ __global__ __launch_bounds__(WR_THREADS) void k_huff_write(const HuffArgs a)
 #pragma unroll
 					for (int q = 0; q < JH_MAX_COMP; ++q) {
 						DCS_AT(dcs, q, WR_THREADS) = 0;
-					}
-#pragma unroll
-					for (int j = 0; j < 8; ++j) {
-						bufs[tid * 8 + j] = make_int4(0, 0, 0, 0);
 					}
 					seg++;
 					if (seg >= nseg) {
@@ -561,7 +570,8 @@ __global__ __launch_bounds__(WR_THREADS) void k_huff_write(const HuffArgs a)
 					const unsigned extra = __builtin_amdgcn_ubfe(wn, 32u - (unsigned)total, (unsigned)cat);
 					val = extend_sign(extra, cat);
 					if (isdc) {
-						val += atomicAdd(dcs + (info >> 24) * WR_THREADS, val);
+						lastold = atomicAdd(dcs + (info >> 24) * WR_THREADS, val);
+						val += lastold;
 					}
 					k = z + run;
 					done = k >= 63;
@@ -576,7 +586,7 @@ __global__ __launch_bounds__(WR_THREADS) void k_huff_write(const HuffArgs a)
 				z = done ? 0 : k + 1;
 				if (done) {
 					fin = true;
-					fblk = (own && blk >= 0 && blk < nblk && blk < limit_blk) ? blk : -1;
+					fblk = (own && blk >= 0 && blk < nblk) ? blk : -1;
 					if (REMAP && fblk >= 0) {
 						fblk = remap_block(rm, fblk);
 					}
@@ -596,7 +606,7 @@ __global__ __launch_bounds__(256) void k_coef_tail_clear(const HuffArgs a)
 	const JhDecodeWork &w = a.w;
 	const int f = blockIdx.y;
 	const size_t nblk = (size_t)a.g.nblk;
-	const size_t first = min((size_t)w.state[f].nblocks, nblk);
+	const size_t first = min((size_t)max(w.state[f].nblocks, w.state[f].ntail), nblk);
 	int4 *p = reinterpret_cast<int4 *>(w.coefs + (size_t)f * nblk * 64);
 	for (size_t i = first * 8 + blockIdx.x * 256u + threadIdx.x; i < nblk * 8; i += (size_t)gridDim.x * 256u) {
 		p[i] = make_int4(0, 0, 0, 0);
@@ -605,12 +615,14 @@ __global__ __launch_bounds__(256) void k_coef_tail_clear(const HuffArgs a)
 
 // A restart segment that ends inside an MCU (truncated data, or an interval that is no multiple of the
 // reference's block group in a single-component scan): the reference does not count that MCU
-// (decoder.c:376-381), so the next segment's first blocks land where its blocks were stored.  In
-// k_huff_write both are stored by unrelated threads; here the later ones are decoded once more, in
-// segment order, after everything else.  One wave per frame, lane 0 decodes: such streams are rare,
+// (decoder.c:376-381), so the next segment's first blocks land where its blocks -- the completed ones and
+// the one the data ran out in -- were stored.  In k_huff_write both are stored by unrelated threads; here the
+// later ones are decoded once more, in segment order, after everything else.  One wave per frame, lane 0 decodes: such streams are rare,
 // a frame without them costs one load.
-__device__ void fixup_segment(const HuffArgs &a, const JhDecFrame *fr, int16_t *fc, const GlobalStream &G,
-                              const unsigned char *luts, uint32_t pos, const uint32_t seg_end, int first, int count)
+// The first `count` blocks of the segment at [pos, seg_end) go to blocks first, first + 1, ...; returns how many
+// of them were complete inside the segment.
+__device__ int fixup_segment(const HuffArgs &a, const JhDecFrame *fr, int16_t *fc, const GlobalStream &G,
+                             const unsigned char *luts, uint32_t pos, const uint32_t seg_end, int first, int count)
 {
 	const JhRemap rm = a.w.rm;
 	int pred[JH_MAX_COMP];
@@ -625,55 +637,55 @@ __device__ void fixup_segment(const HuffArgs &a, const JhDecFrame *fr, int16_t *
 		const int comp = a.g.blk_comp[c];
 		int16_t *dst = n < a.g.nblk ? fc + (size_t)remap_block(rm, n) * 64 : nullptr;
 		int dcv = 0;
-		uint32_t end_pos = pos;
-		// pass 0 proves that the block is complete inside the segment, pass 1 stores it
-		for (int pass = 0; pass < 2; ++pass) {
-			if (pass == 1 && dst) {
-				for (int j = 0; j < 8; ++j) {
-					reinterpret_cast<int4 *>(dst)[j] = make_int4(0, 0, 0, 0);
-				}
+		int z = 0;
+		// read_block() (coeffs.c:196-254): nothing is touched before the DC symbol is in; then the block is
+		// reset and holds the DC difference; the AC coefficients arrive one by one; the prediction is added
+		// once the block is complete (decoder.c:351-355).  Wherever the segment ends, what is there stays.
+		for (;;) {
+			const bool isdc = z == 0;
+			const unsigned char *tab = isdc ? tdc : tac;
+			const uint32_t wj = pos >> 5;
+			const uint32_t wn = bit_window(G.word(wj), G.word(wj + 1), pos);
+			unsigned e = reinterpret_cast<const uint16_t *>(tab)[wn >> (32 - JH_LUT_BITS)];
+			if (e & 0x8000u) {
+				e = long_code(tab, e, wn, isdc);
 			}
-			uint32_t p = pos;
-			int z = 0;
-			for (;;) {
-				const bool isdc = z == 0;
-				const unsigned char *tab = isdc ? tdc : tac;
-				const uint32_t wj = p >> 5;
-				const uint32_t wn = bit_window(G.word(wj), G.word(wj + 1), p);
-				unsigned e = reinterpret_cast<const uint16_t *>(tab)[wn >> (32 - JH_LUT_BITS)];
-				if (e & 0x8000u) {
-					e = long_code(tab, e, wn, isdc);
-				}
-				const int total = (int)(e >> 10), run = (int)((e >> 4) & 63u), cat = (int)(e & 15u);
-				if (e == 0 || p + (uint32_t)total > seg_end) {
-					return;                            // the segment ends inside this block: what is there stays
-				}
-				int val = extend_sign(__builtin_amdgcn_ubfe(wn, 32u - (unsigned)total, (unsigned)cat), cat);
-				if (isdc) {
-#pragma unroll
-					for (int q = 0; q < JH_MAX_COMP; ++q) {
-						val += q == comp ? pred[q] : 0;
+			const int total = (int)(e >> 10), run = (int)((e >> 4) & 63u), cat = (int)(e & 15u);
+			if (e == 0 || pos + (uint32_t)total > seg_end) {
+				return c;
+			}
+			const int val = extend_sign(__builtin_amdgcn_ubfe(wn, 32u - (unsigned)total, (unsigned)cat), cat);
+			const int k = z + run;
+			if (isdc) {
+				dcv = val;
+				if (dst) {
+					for (int j = 0; j < 8; ++j) {
+						reinterpret_cast<int4 *>(dst)[j] = make_int4(0, 0, 0, 0);
 					}
-					dcv = val;
+					dst[0] = (int16_t)val;
 				}
-				const int k = z + run;
-				if (pass == 1 && dst && k < 64 && (isdc || cat != 0)) {
-					dst[k] = (int16_t)val;
-				}
-				p += (uint32_t)total;
-				z = k + 1;
-				if (k >= 63) {
-					break;
-				}
+			} else if (dst && k < 64 && cat != 0) {
+				dst[k] = (int16_t)val;
 			}
-			end_pos = p;
+			pos += (uint32_t)total;
+			z = k + 1;
+			if (k >= 63) {
+				break;
+			}
+		}
+#pragma unroll
+		for (int q = 0; q < JH_MAX_COMP; ++q) {
+			dcv += q == comp ? pred[q] : 0;
+		}
+		if (dst) {
+			dst[0] = (int16_t)dcv;
 		}
 #pragma unroll
 		for (int q = 0; q < JH_MAX_COMP; ++q) {
 			pred[q] = q == comp ? dcv : pred[q];
 		}
-		pos = end_pos;
 	}
+	return count;
 }
 
 __global__ __launch_bounds__(64) void k_huff_fixup(const HuffArgs a)
@@ -693,6 +705,7 @@ __global__ __launch_bounds__(64) void k_huff_fixup(const HuffArgs a)
 	const GlobalStream G{w.cs + fr->cs_off};
 	int16_t *fc = w.coefs + (size_t)f * (w.rm.mode ? w.rm.nblk_full : a.g.nblk) * 64;
 	const int lane = threadIdx.x;
+	uint32_t handled = 0;                                  // segments below this index are settled
 	for (uint32_t s0 = 0; s0 < nseg; s0 += 64) {
 		const uint32_t s = s0 + lane;
 		const unsigned long long ev = s < nseg ? drop[s] : 0ull;
@@ -703,10 +716,21 @@ __global__ __launch_bounds__(64) void k_huff_fixup(const HuffArgs a)
 			const uint32_t lo = __shfl((uint32_t)ev, src, 64), hi = __shfl((uint32_t)(ev >> 32), src, 64);
 			if (lane == 0) {
 				const unsigned long long e = ((unsigned long long)hi << 32) | lo;
-				const uint32_t sg = s0 + (uint32_t)src;
-				fixup_segment(a, fr, fc, G, luts, seg_start[sg] * 8u, min(seg_start[sg + 1] * 8u, total_bits),
-				              (int)(e >> 8), (int)(e & 0xffu));
+				const int first = (int)(e >> 8);
+				// Segment sg starts over the MCU its predecessor left unfinished.  While a segment does not
+				// complete that MCU either, the one behind it starts there again (context->mblocks stands still,
+				// decoder.c:376-381): the whole run is redone here in stream order, each segment's first MCU
+				// (or what there is of it) over what the earlier ones left.
+				for (uint32_t sg = s0 + (uint32_t)src; sg >= handled && sg < nseg; ++sg) {
+					const int done = fixup_segment(a, fr, fc, G, luts, seg_start[sg] * 8u, min(seg_start[sg + 1] * 8u, total_bits),
+					                               first, a.g.B);
+					handled = sg + 1;
+					if (done == a.g.B) {
+						break;
+					}
+				}
 			}
+			handled = __shfl(handled, 0, 64);
 		}
 	}
 }

@@ -48,6 +48,8 @@ struct JhDecState {               // written by the device
 	                              // inconsistent after the walk rounds, 4 a walk had to decode too much by itself, 16 test hook
 	uint32_t term_marker;         // second byte of the marker at term_pos (0xd9 = EOI)
 	uint32_t ndrop;               // restart segments that ended inside an MCU (k_huff_fixup has work)
+	uint32_t ntail;               // the LAST segment ended inside an MCU: blocks below this index hold what the
+	                              // reference leaves of it (decoder.c:347-355) and are not cleared
 };
 
 // A scan that codes ONE component of a multi-component frame (non-interleaved order, decoder.c:274-302)

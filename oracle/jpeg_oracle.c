@@ -643,10 +643,13 @@ static int read_block(bitr *r, const hufftab *dc, const hufftab *ac, int32_t *bl
 			break;   /* EOB */
 		}
 		i += run;
-		if (i > 63) {
-			return ORC_ERR_NO_MORE_DATA;   /* the reference would index zigzag[] out of range */
+		if (i <= 63) {
+			blk[zz[i]] = orc_decode_coeff(cat, extra);
 		}
-		blk[zz[i]] = orc_decode_coeff(cat, extra);
+		/* i > 63 (a zero run past the end of the block, damaged data): the reference reads zigzag[] out of
+		 * range and stores the value wherever that byte points (undefined behaviour, coeffs.c:246-247); its
+		 * CONTROL FLOW is defined all the same: rem drops to 0 or below, the block is complete and decoding
+		 * goes on with the next one.  The store is left out here. */
 		i++;
 		rem -= run + 1;
 	} while (rem > 0);

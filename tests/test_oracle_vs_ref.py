@@ -136,3 +136,59 @@ def test_truncated_and_garbage_streams_agree(oracle, reference):
     e1, _, _ = oracle.decode(jpg[:-2])
     e2, _, _ = reference.decode(jpg[:-2])
     assert e1 == e2 and e1 != 0
+
+
+def test_zero_run_past_the_end_of_a_block_ends_the_block(oracle, reference):
+    """Damaged data: a zero run that carries the coefficient pointer past 63.  The reference indexes zigzag[]
+    out of range there (coeffs.c:246-247, undefined behaviour: a stray store), but its control flow is
+    defined: `rem` is used up, the block is complete, decoding goes on.  The oracle follows that flow and
+    leaves the store out.  With ZRL as the overshooting symbol the stray store writes a zero into a block
+    that is zero (or is reset later), so the compiled reference and the oracle must agree on everything;
+    with a nonzero value they must agree on every block but the damaged one."""
+    from tests.damaged import zero_run_past_block_end
+    for value_cat in (0, 1):
+        jpg, want = zero_run_past_block_end(oracle, value_cat)
+        eo, po, io = oracle.decode(jpg)
+        er, pr, ir = reference.decode(jpg)
+        assert eo == 0 and er == 0
+        co, cr = io.comps[0]["coef"], ir.comps[0]["coef"]
+        for b, vals in want.items():
+            exp = np.zeros(64, np.int32)
+            for k, v in vals.items():
+                exp[k] = v
+            assert np.array_equal(co[b], exp) and np.array_equal(cr[b], exp), (value_cat, b)
+        assert not co[0].any()                           # the store is left out
+        if value_cat == 0:
+            assert np.array_equal(co, cr) and np.array_equal(po, pr)
+
+
+def test_data_that_runs_out_inside_an_mcu(oracle, reference):
+    """decoder.c:347-355, 376-381, coeffs.c:222: the blocks of the unfinished MCU that were completed stay (with
+    prediction), the block the data ran out in stays with its DC difference and the AC coefficients read so
+    far, the MCU is not counted, and the next restart interval starts over it.  The oracle against the compiled
+    reference on streams cut at many places, with and without restart markers, EOI appended."""
+    img = synth_image(96, 64, 3, 8, seed=77)
+    for H, V, ri in ((2, 2, 0), (2, 1, 2), (1, 1, 3)):
+        err, jpg, _ = oracle.encode(img, P=8, H=H, V=V, q=90, optimize=1, restart_interval=ri)
+        assert err == 0
+        sos = jpg.index(b"\xff\xda")
+        start = sos + 2 + ((jpg[sos + 2] << 8) | jpg[sos + 3])
+        for cut in range(start + 5, len(jpg) - 2, max(1, (len(jpg) - start) // 37)):
+            bad = jpg[:cut] + b"\xff\xd9"
+            eo, po, io = oracle.decode(bad)
+            er, pr, ir = reference.decode(bad)
+            assert eo == er
+            if eo == 0:
+                assert _same_coefs(io, ir), (H, V, ri, cut)
+                assert np.array_equal(po, pr)
+    # restart intervals whose data is cut in the middle of the stream (not only at its end)
+    err, jpg, _ = oracle.encode(img, P=8, H=2, V=2, q=90, optimize=0, restart_interval=2)
+    marks = [i for i in range(len(jpg) - 1) if jpg[i] == 0xFF and 0xD0 <= jpg[i + 1] <= 0xD7]
+    for m in marks[1:8]:
+        for back in (1, 3, 9):
+            bad = jpg[:m - back] + jpg[m:]
+            eo, po, io = oracle.decode(bad)
+            er, pr, ir = reference.decode(bad)
+            assert eo == er == 0
+            assert _same_coefs(io, ir), (m, back)
+            assert np.array_equal(po, pr)
