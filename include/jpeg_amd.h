@@ -106,7 +106,8 @@ int jpeg_hip_selftest_divide(int device, int ties_per_divisor, unsigned seed, un
  *            sub-sequences; per restart interval where markers exist), DC un-prediction
  *            (decoder.c:351-355), then the fused epilogue (dequantise, IDCT, level shift, up-sampling
  *            by replication, YCbCr/YCCK -> RGB, roundf, clamp) writing the PPM/PGM body.
- *   sync     waits and returns per-frame RET_* codes.
+ *   sync     waits for that run (an event, not the whole stream: work queued behind it is not waited
+ *            for) and returns per-frame RET_* codes.
  */
 typedef struct jpeg_hip_decoder jpeg_hip_decoder;
 
@@ -114,6 +115,17 @@ int  jpeg_hip_decoder_create(jpeg_hip_decoder **dec, int device);
 void jpeg_hip_decoder_destroy(jpeg_hip_decoder *dec);
 int  jpeg_hip_decoder_prepare(jpeg_hip_decoder *dec, int nframes,
                               const uint8_t *const *jpg, const size_t *jpg_len);
+/* The same for codestreams that lie in page-locked host memory, close together -- a Motion JPEG file read
+ * into one buffer from jpeg_hip_host_alloc() (or hipHostMalloc / hipHostRegister): the span of memory that
+ * holds the frames goes to the device in one DMA from where it lies (no staging copy), queued on a stream of
+ * the decoder's own; prepare returns without waiting and run() makes its stream wait.  The memory must stay
+ * as it is until sync() has returned.  Frames scattered over memory (the span more than twice their bytes)
+ * take the staged path of jpeg_hip_decoder_prepare().  The reference reads with fread() from a FILE*
+ * (io.c:89-95); this is the memory-side replacement of that for callers that own their I/O buffers. */
+int  jpeg_hip_decoder_prepare_pinned(jpeg_hip_decoder *dec, int nframes,
+                                     const uint8_t *const *jpg, const size_t *jpg_len);
+void *jpeg_hip_host_alloc(size_t bytes);              /* page-locked host memory, NULL on failure */
+void jpeg_hip_host_free(void *p);
 int  jpeg_hip_decoder_info(const jpeg_hip_decoder *dec, jpeg_hip_frame_info *info);
 /* bytes one decoded frame occupies: X*Y*out_components*sample_bytes */
 size_t jpeg_hip_decoder_frame_bytes(const jpeg_hip_decoder *dec);

@@ -27,6 +27,7 @@ MAX_COMP = 4
 EXPORTS = [
     "jpeg_hip_device_count", "jpeg_hip_version", "jpeg_hip_parse_info",
     "jpeg_hip_decoder_create", "jpeg_hip_decoder_destroy", "jpeg_hip_decoder_prepare",
+    "jpeg_hip_decoder_prepare_pinned", "jpeg_hip_host_alloc", "jpeg_hip_host_free",
     "jpeg_hip_decoder_info", "jpeg_hip_decoder_frame_bytes", "jpeg_hip_decoder_run",
     "jpeg_hip_decoder_sync", "jpeg_hip_decoder_get_coefficients", "jpeg_hip_decoder_set_timing",
     "jpeg_hip_decoder_get_timing", "jpeg_hip_decoder_ecs_bytes", "jpeg_hip_decoder_get_stats",
@@ -107,6 +108,11 @@ def lib():
         L.jpeg_hip_decoder_destroy.argtypes = [vp]
         L.jpeg_hip_decoder_destroy.restype = None
         L.jpeg_hip_decoder_prepare.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(sz)]
+        L.jpeg_hip_decoder_prepare_pinned.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(sz)]
+        L.jpeg_hip_host_alloc.argtypes = [sz]
+        L.jpeg_hip_host_alloc.restype = vp
+        L.jpeg_hip_host_free.argtypes = [vp]
+        L.jpeg_hip_host_free.restype = None
         L.jpeg_hip_decoder_info.argtypes = [vp, C.POINTER(FrameInfo)]
         L.jpeg_hip_decoder_frame_bytes.argtypes = [vp]
         L.jpeg_hip_decoder_frame_bytes.restype = sz
@@ -181,6 +187,69 @@ def parse_info(jpg, tolerant=False):
     return err, fi
 
 
+class PinnedBuffer:
+    """Page-locked host memory from the library (jpeg_hip_host_alloc): what a capture or I/O layer reads a Motion
+    JPEG file into, so that its frames go to the device without a staging copy."""
+
+    def __init__(self, nbytes):
+        self.L = lib()
+        self.nbytes = nbytes
+        self.addr = self.L.jpeg_hip_host_alloc(nbytes)
+        if not self.addr:
+            raise JpegError(RET_FAILURE_MEMORY_ALLOCATION, "jpeg_hip_host_alloc")
+
+    def view(self):
+        return (C.c_ubyte * self.nbytes).from_address(self.addr)
+
+    def close(self):
+        if self.addr:
+            self.L.jpeg_hip_host_free(self.addr)
+            self.addr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class PinnedFrames:
+    """Frames (offset, length) inside a PinnedBuffer; slicing gives the frames of a batch or of a rank's shard."""
+
+    def __init__(self, buf, offsets, lengths):
+        self.buf, self.offsets, self.lengths = buf, list(offsets), list(lengths)
+
+    @classmethod
+    def from_frames(cls, frames):
+        """Copy codestreams (bytes) back to back into a new pinned buffer, as they lie in a Motion JPEG file."""
+        lengths = [len(f) for f in frames]
+        buf = PinnedBuffer(max(1, sum(lengths)))
+        dst = np.frombuffer(buf.view(), dtype=np.uint8)
+        offsets, at = [], 0
+        for f in frames:
+            dst[at:at + len(f)] = np.frombuffer(f, dtype=np.uint8)
+            offsets.append(at)
+            at += len(f)
+        return cls(buf, offsets, lengths)
+
+    def __len__(self):
+        return len(self.offsets)
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return PinnedFrames(self.buf, self.offsets[i], self.lengths[i])
+        return C.string_at(self.buf.addr + self.offsets[i], self.lengths[i])
+
+    def nbytes(self):
+        return sum(self.lengths)
+
+    def c_arrays(self):
+        n = len(self.offsets)
+        ptrs = (C.c_void_p * n)(*[self.buf.addr + o for o in self.offsets])
+        lens = (C.c_size_t * n)(*self.lengths)
+        return ptrs, lens
+
+
 class Decoder:
     """Batch decoder: JPEG codestreams (same geometry) -> PPM/PGM bodies resident in HBM.
 
@@ -208,12 +277,19 @@ class Decoder:
             pass
 
     def prepare(self, jpgs):
-        jpgs = [bytes(j) for j in jpgs]
-        self._keep = jpgs
-        n = len(jpgs)
-        ptrs = (C.c_char_p * n)(*jpgs)
-        lens = (C.c_size_t * n)(*[len(j) for j in jpgs])
-        err = self.L.jpeg_hip_decoder_prepare(self.h, n, ptrs, lens)
+        """jpgs: codestreams as bytes-like objects, or a PinnedFrames (frames in page-locked memory: no staging copy)"""
+        if isinstance(jpgs, PinnedFrames):
+            self._keep = jpgs
+            n = len(jpgs)
+            ptrs, lens = jpgs.c_arrays()
+            err = self.L.jpeg_hip_decoder_prepare_pinned(self.h, n, ptrs, lens)
+        else:
+            jpgs = [bytes(j) for j in jpgs]
+            self._keep = jpgs
+            n = len(jpgs)
+            ptrs = (C.c_char_p * n)(*jpgs)
+            lens = (C.c_size_t * n)(*[len(j) for j in jpgs])
+            err = self.L.jpeg_hip_decoder_prepare(self.h, n, ptrs, lens)
         if err:
             raise JpegError(err, "jpeg_hip_decoder_prepare")
         self.n = n

@@ -16,6 +16,7 @@
 #include <string>
 #include <functional>
 #include <mutex>
+#include <atomic>
 #include "../../include/jpeg_amd.h"
 #include "common.hpp"
 #include "codestream.hpp"
@@ -214,7 +215,9 @@ struct jpeg_hip_decoder {
 	std::vector<DecPass> pass;
 	std::vector<int> parse_err;
 	std::vector<size_t> ecs_len;
-	std::vector<size_t> file_off, file_len;   // the frames inside h_stage (valid until the next prepare)
+	std::vector<size_t> file_off, file_len;   // the frames inside d_raw (valid until the next prepare)
+	std::vector<const uint8_t *> file_ptr;    // and on the host: inside h_stage, the caller's pinned memory, or patched[]
+	std::vector<std::vector<uint8_t>> patched;    // private copies of frames sync() had to cut (caller's memory is never written)
 	std::vector<size_t> spliced;              // bytes sync() cut out of a frame behind stray markers (see there)
 	// device
 	uint8_t *d_raw = nullptr;
@@ -226,6 +229,9 @@ struct jpeg_hip_decoder {
 	void *last_out = nullptr;
 	size_t last_stride = 0;
 	hipStream_t last_stream = nullptr;
+	hipStream_t copy_stream = nullptr;    // the codestreams' DMA runs here, beside the kernels of another decoder
+	hipEvent_t uploaded = nullptr;        // ... and run() makes its stream wait for this
+	hipEvent_t done = nullptr;            // end of run()'s kernels: sync() waits for it, not for the whole stream
 	bool ran = false;
 	int debug = 0;
 	bool tolerant = false;
@@ -276,6 +282,12 @@ extern "C" int jpeg_hip_decoder_create(jpeg_hip_decoder **dec, int device)
 	d->device = device;
 	d->pass.reserve(JH_MAX_COMP);                          // addresses of the passes stay put (see cap)
 	memset(&d->g, 0, sizeof d->g);
+	if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&d->copy_stream, hipStreamNonBlocking) != hipSuccess ||
+	    hipEventCreateWithFlags(&d->uploaded, hipEventDisableTiming) != hipSuccess ||
+	    hipEventCreateWithFlags(&d->done, hipEventDisableTiming) != hipSuccess) {
+		delete d;
+		return RET_FAILURE_MEMORY_ALLOCATION;
+	}
 	*dec = d;
 	return RET_SUCCESS;
 }
@@ -284,9 +296,21 @@ extern "C" void jpeg_hip_decoder_destroy(jpeg_hip_decoder *dec)
 {
 	if (dec) {
 		hipSetDevice(dec->device);
+		if (dec->copy_stream) {
+			hipStreamSynchronize(dec->copy_stream);
+		}
 		dec->release();
 		if (dec->h_stage) {
 			hipHostFree(dec->h_stage);
+		}
+		if (dec->uploaded) {
+			hipEventDestroy(dec->uploaded);
+		}
+		if (dec->done) {
+			hipEventDestroy(dec->done);
+		}
+		if (dec->copy_stream) {
+			hipStreamDestroy(dec->copy_stream);
 		}
 		delete dec;
 	}
@@ -406,16 +430,21 @@ static int parse_frame(const uint8_t *p, size_t n, JhHeader *h, std::vector<Scan
 // headers and scans of frame f: parse_frame() for codestreams, or the caller's description (jpeg_hip_read_scan)
 typedef std::function<int(int, JhHeader *, std::vector<ScanDesc> *)> FrameParser;
 
+// pinned (optional, in/out): the frames lie in page-locked host memory, close together (a Motion JPEG file read
+// into one pinned buffer): then the span that holds them goes to the device in ONE DMA from where it lies, and the
+// frames keep their distances there (the kernels take any offset: their 4 KiB chunks are cut by every frame's
+// own bounds).  The parser may clear the flag; a span that is mostly holes clears it too.
 static int decoder_prepare(jpeg_hip_decoder *dec, int nframes, const uint8_t *const *jpg, const size_t *jpg_len,
-                           const FrameParser &parse)
+                           const FrameParser &parse, bool *pinned = nullptr)
 {
 	if (!dec || nframes <= 0) {
 		return RET_FAILURE_LOGIC_ERROR;
 	}
 	HIPCHK(hipSetDevice(dec->device));
 	if (dec->ran) {
-		HIPCHK(hipStreamSynchronize(dec->last_stream));    // the buffers are about to be reused
+		HIPCHK(hipEventSynchronize(dec->done));            // the buffers are about to be reused
 	}
+	HIPCHK(hipEventSynchronize(dec->uploaded));            // ... and the staging buffer (prepare() twice in a row)
 	dec->ran = false;
 	dec->nframes = 0;                                      // not prepared until everything below has succeeded
 	dec->parse_err.assign(nframes, 0);
@@ -465,20 +494,51 @@ static int decoder_prepare(jpeg_hip_decoder *dec, int nframes, const uint8_t *co
 			}
 		}
 		dec->parse_err[f] = err;
-		file_off[f] = raw_off;
 		if (!err) {
 			for (int t = 0; t < 4; ++t) {
 				for (int z = 0; z < 64; ++z) {
 					quant[f].q[t][z] = h.Q[t][jh_zigzag[z]];
 				}
 			}
-			raw_off = align_up(raw_off + jpg_len[f] + 32, 4096);   // chunk aligned: frames never share a chunk
+		}
+	}
+	// where the frames go in d_raw (after the parsing: it may hand back a shorter file, in other memory)
+	dec->file_len.assign(jpg_len, jpg_len + nframes);
+	dec->file_ptr.assign(nframes, nullptr);
+	dec->patched.clear();
+	dec->patched.resize(nframes);
+	const uint8_t *span_lo = nullptr, *span_hi = nullptr;
+	bool direct = pinned && *pinned;
+	if (direct) {
+		size_t sum = 0;
+		for (int f = 0; f < nframes; ++f) {
+			span_lo = !span_lo || jpg[f] < span_lo ? jpg[f] : span_lo;
+			span_hi = !span_hi || jpg[f] + jpg_len[f] > span_hi ? jpg[f] + jpg_len[f] : span_hi;
+			sum += jpg_len[f];
+		}
+		const size_t span = (size_t)(span_hi - span_lo);
+		direct = span <= 2 * sum + (1u << 20) && span + 8192 <= 0xf0000000ull;
+	}
+	if (pinned) {
+		*pinned = direct;
+	}
+	const size_t lead = direct ? (size_t)((uintptr_t)span_lo & 4095) : 0;      // the span keeps its place in its page
+	for (int f = 0; f < nframes; ++f) {
+		if (direct) {
+			file_off[f] = lead + (size_t)(jpg[f] - span_lo);
+			continue;
+		}
+		file_off[f] = raw_off;
+		if (!dec->parse_err[f]) {
+			raw_off = align_up(raw_off + jpg_len[f] + 32, 4096);   // a frame starts a 4 KiB chunk of the un-stuffing kernels
 			if (raw_off > 0xf0000000ull) {
 				return RET_FAILURE_OVERFLOW_ERROR;               // 32-bit offsets: split the batch
 			}
 		}
 	}
-	dec->file_len.assign(jpg_len, jpg_len + nframes);      // after the parsing: it may hand back a shorter file
+	if (direct) {
+		raw_off = align_up(lead + (size_t)(span_hi - span_lo) + 32, 4096);
+	}
 	lap("parse");
 	if (!have_geom) {
 		// nothing decodable: report the first parse error
@@ -684,48 +744,87 @@ static int decoder_prepare(jpeg_hip_decoder *dec, int nframes, const uint8_t *co
 	HIPCHK(dec->grow((void **)&dec->d_raw, dec->raw_bytes));
 	HIPCHK(dec->grow((void **)&dec->d_quant, nframes * sizeof(JhQuant)));
 	HIPCHK(dec->grow((void **)&dec->d_coefs, (size_t)nframes * G.nblk * 64 * sizeof(int16_t)));
-	// The codestreams go through ONE pinned staging buffer (kept between calls) and one DMA: the caller's
-	// memory is pageable as a rule, and a copy per frame from pageable memory runs at a third of the link's
-	// rate.  Frames are laid out as on the device, the gaps between them zero; a few threads fill it.
-	if (dec->stage_bytes < dec->raw_bytes) {
-		if (dec->h_stage) {
-			hipHostFree(dec->h_stage);
-			dec->h_stage = nullptr;
-			dec->stage_bytes = 0;
+	if (direct) {
+		// one DMA from the caller's pinned memory, on the decoder's copy stream; run() waits for it on its stream
+		const size_t span = (size_t)(span_hi - span_lo);
+		if (lead) {
+			HIPCHK(hipMemsetAsync(dec->d_raw, 0, lead, dec->copy_stream));
 		}
-		const size_t want = dec->raw_bytes + dec->raw_bytes / 4;
-		HIPCHK(hipHostMalloc((void **)&dec->h_stage, want, hipHostMallocDefault));
-		dec->stage_bytes = want;
-	}
-	{
+		HIPCHK(hipMemcpyAsync(dec->d_raw + lead, span_lo, span, hipMemcpyHostToDevice, dec->copy_stream));
+		HIPCHK(hipMemsetAsync(dec->d_raw + lead + span, 0, dec->raw_bytes - lead - span, dec->copy_stream));
+		for (int f = 0; f < nframes; ++f) {
+			dec->file_ptr[f] = jpg[f];                         // sync() reads headers there: valid until it has returned
+		}
+	} else {
+		// The codestreams go through ONE pinned staging buffer (kept between calls): the caller's memory is
+		// pageable as a rule, and a copy per frame from pageable memory runs at a third of the link's rate.
+		// Frames are laid out as on the device, the gaps between them zero.  A few threads fill it piece by piece,
+		// and the DMA of a piece starts (copy stream) as soon as the piece and those before it are filled.
+		if (dec->stage_bytes < dec->raw_bytes) {
+			if (dec->h_stage) {
+				hipHostFree(dec->h_stage);
+				dec->h_stage = nullptr;
+				dec->stage_bytes = 0;
+			}
+			const size_t want = dec->raw_bytes + dec->raw_bytes / 4;
+			HIPCHK(hipHostMalloc((void **)&dec->h_stage, want, hipHostMallocDefault));
+			dec->stage_bytes = want;
+		}
 		uint8_t *stage = dec->h_stage;
 		const size_t total = dec->raw_bytes;
-		auto fill = [&](int f0, int f1) {
-			for (int f = f0; f < f1; ++f) {
-				const size_t begin = file_off[f];
-				const size_t end = f + 1 < nframes ? file_off[f + 1] : total;
-				size_t used = 0;
-				if (dec->parse_err[f] == 0) {
-					memcpy(stage + begin, jpg[f], jpg_len[f]);
-					used = jpg_len[f];
+		const int nthr = total > (8u << 20) && nframes >= 16 ? 6 : 1;
+		const int npiece = nthr == 1 ? 1 : (nframes < 4 * nthr ? nthr : 4 * nthr);
+		auto piece_first = [&](int pc) { return (int)((long long)nframes * pc / npiece); };
+		std::vector<std::atomic<int>> filled(npiece);
+		for (std::atomic<int> &a : filled) {
+			a.store(0, std::memory_order_relaxed);
+		}
+		std::atomic<int> next_piece(0);
+		auto fill = [&]() {
+			for (;;) {
+				const int pc = next_piece.fetch_add(1);
+				if (pc >= npiece) {
+					return;
 				}
-				memset(stage + begin + used, 0, end - begin - used);
+				for (int f = piece_first(pc); f < piece_first(pc + 1); ++f) {
+					const size_t begin = file_off[f];
+					const size_t end = f + 1 < nframes ? file_off[f + 1] : total;
+					size_t used = 0;
+					if (dec->parse_err[f] == 0) {
+						memcpy(stage + begin, jpg[f], jpg_len[f]);
+						used = jpg_len[f];
+					}
+					memset(stage + begin + used, 0, end - begin - used);
+				}
+				filled[pc].store(1, std::memory_order_release);
 			}
 		};
-		const int nthr = total > (8u << 20) && nframes >= 8 ? 4 : 1;
+		std::vector<std::thread> pool;
+		for (int t = 1; t < nthr; ++t) {
+			pool.emplace_back(fill);
+		}
+		hipError_t up = hipSuccess;
 		if (nthr == 1) {
-			fill(0, nframes);
-		} else {
-			std::vector<std::thread> pool;
-			for (int t = 0; t < nthr; ++t) {
-				pool.emplace_back(fill, (int)((long long)nframes * t / nthr), (int)((long long)nframes * (t + 1) / nthr));
+			fill();
+		}
+		for (int pc = 0; pc < npiece; ++pc) {
+			while (!filled[pc].load(std::memory_order_acquire)) {
+				std::this_thread::yield();
 			}
-			for (std::thread &th : pool) {
-				th.join();
+			const size_t a = file_off[piece_first(pc)], b = pc + 1 < npiece ? file_off[piece_first(pc + 1)] : total;
+			if (up == hipSuccess && b > a) {
+				up = hipMemcpyAsync(dec->d_raw + a, stage + a, b - a, hipMemcpyHostToDevice, dec->copy_stream);
 			}
 		}
-		HIPCHK(hipMemcpy(dec->d_raw, stage, total, hipMemcpyHostToDevice));
+		for (std::thread &th : pool) {
+			th.join();
+		}
+		HIPCHK(up);
+		for (int f = 0; f < nframes; ++f) {
+			dec->file_ptr[f] = stage + file_off[f];
+		}
 	}
+	HIPCHK(hipEventRecord(dec->uploaded, dec->copy_stream));
 	HIPCHK(hipMemcpy(dec->d_quant, quant.data(), nframes * sizeof(JhQuant), hipMemcpyHostToDevice));
 	lap("upload");
 
@@ -787,6 +886,41 @@ extern "C" int jpeg_hip_decoder_prepare(jpeg_hip_decoder *dec, int nframes,
 	});
 }
 
+extern "C" int jpeg_hip_decoder_prepare_pinned(jpeg_hip_decoder *dec, int nframes,
+                                               const uint8_t *const *jpg, const size_t *jpg_len)
+{
+	if (!dec || nframes <= 0 || !jpg || !jpg_len) {
+		return RET_FAILURE_LOGIC_ERROR;
+	}
+	bool pinned = true, patch = false;
+	int err = decoder_prepare(dec, nframes, jpg, jpg_len, [&](int f, JhHeader *h, std::vector<ScanDesc> *sc) {
+		size_t cut[2] = {0, 0};
+		const int e = parse_frame(jpg[f], jpg_len[f], h, sc, dec->tolerant, cut);
+		if (e == PARSE_SPLICE) {
+			patch = true;                                  // a damaged frame that needs a patched copy: the staged path makes it
+			pinned = false;
+		}
+		return e;
+	}, &pinned);
+	if (patch) {
+		err = jpeg_hip_decoder_prepare(dec, nframes, jpg, jpg_len);
+	}
+	return err;
+}
+
+extern "C" void *jpeg_hip_host_alloc(size_t bytes)
+{
+	void *p = nullptr;
+	return hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) == hipSuccess ? p : nullptr;
+}
+
+extern "C" void jpeg_hip_host_free(void *p)
+{
+	if (p) {
+		hipHostFree(p);
+	}
+}
+
 extern "C" int jpeg_hip_decoder_info(const jpeg_hip_decoder *dec, jpeg_hip_frame_info *info)
 {
 	if (!dec || dec->nframes == 0) {
@@ -832,14 +966,15 @@ static int decoder_launch(jpeg_hip_decoder *dec, hipStream_t s)
 		}
 	}
 	if (dec->coefs_only) {
-		return RET_SUCCESS;                                // jpeg_hip_read_scan: the coefficients are the result
+		// jpeg_hip_read_scan: the coefficients are the result
+		return hipEventRecord(dec->done, s) == hipSuccess ? RET_SUCCESS : RET_FAILURE_LOGIC_ERROR;
 	}
 	dec->timer.begin("k_decode_pixels", s);
 	if (jh_launch_decode_pixels(dec->g, dec->nframes, dec->d_coefs, dec->d_quant, dec->last_out, dec->last_stride, s)) {
 		return RET_FAILURE_LOGIC_ERROR;
 	}
 	dec->timer.end(s);
-	return RET_SUCCESS;
+	return hipEventRecord(dec->done, s) == hipSuccess ? RET_SUCCESS : RET_FAILURE_LOGIC_ERROR;
 }
 
 extern "C" int jpeg_hip_decoder_run(jpeg_hip_decoder *dec, void *d_samples, size_t frame_stride, void *stream)
@@ -855,6 +990,7 @@ extern "C" int jpeg_hip_decoder_run(jpeg_hip_decoder *dec, void *d_samples, size
 	dec->last_stride = frame_stride;
 	dec->last_stream = (hipStream_t)stream;
 	dec->timer.reset();
+	HIPCHK(hipStreamWaitEvent(dec->last_stream, dec->uploaded, 0));    // the codestreams' DMA (copy stream)
 	int err = decoder_launch(dec, dec->last_stream);
 	dec->ran = err == RET_SUCCESS;
 	return err;
@@ -869,7 +1005,7 @@ extern "C" int jpeg_hip_decoder_sync(jpeg_hip_decoder *dec, int *frame_status)
 		frame_status[f] = RET_FAILURE_LOGIC_ERROR;         // what every early return below leaves behind
 	}
 	HIPCHK(hipSetDevice(dec->device));
-	HIPCHK(hipStreamSynchronize(dec->last_stream));
+	HIPCHK(hipEventSynchronize(dec->done));                // this run's kernels, not what the caller queued behind them
 	for (int attempt = 0;; ++attempt) {
 		for (DecPass &ps : dec->pass) {
 			HIPCHK(hipMemcpy(ps.state.data(), ps.d_state, dec->nframes * sizeof(JhDecState), hipMemcpyDeviceToHost));
@@ -910,7 +1046,7 @@ extern "C" int jpeg_hip_decoder_sync(jpeg_hip_decoder *dec, int *frame_status)
 		// segments by their length, bytes between markers) and, when it arrives at an RSTn, decodes on from
 		// there (decoder.c:622-633) with the MCU counter where it stood.  For the decoder that is the stream with
 		// the skipped bytes cut out: done here on the host copy of the frame, and the batch runs once more.
-		if (!again && dec->pass.size() == 1 && dec->pass[0].comp == -1 && !dec->coefs_only && dec->h_stage) {
+		if (!again && dec->pass.size() == 1 && dec->pass[0].comp == -1 && !dec->coefs_only) {
 			DecPass &ps = dec->pass[0];
 			bool cut = false;
 			for (int f = 0; f < dec->nframes; ++f) {
@@ -919,13 +1055,23 @@ extern "C" int jpeg_hip_decoder_sync(jpeg_hip_decoder *dec, int *frame_status)
 				if (dec->parse_err[f] || (ds.status & JH_ST_SEG_OVERFLOW) || ds.term_pos + 1 >= fr.raw_end || ds.term_marker == 0xd9) {
 					continue;
 				}
-				uint8_t *file = dec->h_stage + dec->file_off[f];
+				const uint8_t *orig = dec->file_ptr[f];
 				const size_t len = dec->file_len[f], rel = ds.term_pos - dec->file_off[f];
 				size_t rst = 0;
-				if (rel >= len || jh_walk_to_restart(file, len, rel, dec->tolerant, &rst) != RET_SUCCESS || rst <= rel) {
+				if (!orig || rel >= len || jh_walk_to_restart(orig, len, rel, dec->tolerant, &rst) != RET_SUCCESS || rst <= rel) {
 					continue;                                  // EOI, or something that ends the decoding: settled below
 				}
 				const size_t removed = rst - rel;
+				uint8_t *file;
+				if (dec->h_stage && orig >= dec->h_stage && orig < dec->h_stage + dec->stage_bytes) {
+					file = dec->h_stage + (orig - dec->h_stage);       // our staging copy
+				} else {
+					if (dec->patched[f].empty()) {
+						dec->patched[f].assign(orig, orig + len);      // the caller's memory is not ours to change
+					}
+					file = dec->patched[f].data();
+					dec->file_ptr[f] = file;
+				}
 				memmove(file + rel, file + rst, len - rst);
 				memset(file + len - removed, 0, removed);
 				HIPCHK(hipMemcpy(dec->d_raw + dec->file_off[f] + rel, file + rel, len - rel, hipMemcpyHostToDevice));
@@ -946,7 +1092,7 @@ extern "C" int jpeg_hip_decoder_sync(jpeg_hip_decoder *dec, int *frame_status)
 		if (err) {
 			return err;
 		}
-		HIPCHK(hipStreamSynchronize(dec->last_stream));
+		HIPCHK(hipEventSynchronize(dec->done));
 	}
 	int worst = RET_SUCCESS;
 	for (int f = 0; f < dec->nframes; ++f) {
@@ -969,10 +1115,10 @@ extern "C" int jpeg_hip_decoder_sync(jpeg_hip_decoder *dec, int *frame_status)
 				// tables would change the image already made.
 				st = RET_FAILURE_FILE_UNSUPPORTED;
 				JhHeader h0, h1;
-				const uint8_t *file = dec->h_stage + dec->file_off[f];
+				const uint8_t *file = dec->file_ptr[f];
 				const size_t len = dec->file_len[f];
 				bool eoi = false;
-				if (dec->h_stage && jh_parse_headers(file, len, &h0, dec->tolerant) == RET_SUCCESS) {
+				if (file && jh_parse_headers(file, len, &h0, dec->tolerant) == RET_SUCCESS) {
 					h1 = h0;
 					const int e = jh_parse_next_scan(file, len, ds.term_pos - dec->file_off[f], &h1, &eoi);
 					if (e == RET_SUCCESS && eoi && memcmp(h0.Q, h1.Q, sizeof h0.Q) == 0) {

@@ -70,25 +70,42 @@ def decode_batches(frames, batch=256, device=0):
 
 
 def decode_stream(frames, batch=256, device=0):
-    """The same, double-buffered: two decoder objects take turns, and while one
-    batch is decoded on a stream of its own, a helper thread parses the next batch's headers and uploads
-    its codestreams through the library's pinned staging buffer.  Yields (tensor, status) in order; the
-    tensor of a batch stays valid until the batch after the next one has been yielded."""
+    """The same, pipelined: two decoder objects take turns.  A helper thread parses the
+    next batch's headers and queues its upload (copy stream of the decoder: a DMA from the library's pinned
+    staging buffer, or straight from the caller's memory when `frames` is a binding.PinnedFrames) while the
+    kernels of this batch run; and the kernels of batch i+1 are queued behind those of batch i BEFORE the caller
+    waits for batch i, so the device does not idle while Python looks at statuses.  Yields (tensor, status) in
+    order; the tensor of a batch stays valid until the batch after the next one has been yielded."""
     from concurrent.futures import ThreadPoolExecutor
     torch = binding._torch()
     decs, stream = _stream_decoders(device)
     chunks = [frames[i:i + batch] for i in range(0, len(frames), batch)]
+    if not chunks:
+        return
     with ThreadPoolExecutor(max_workers=1) as pool:
-        fut = pool.submit(decs[0].prepare, chunks[0]) if chunks else None
+        fut = pool.submit(decs[0].prepare, chunks[0])
         try:
+            fut.result()
+            fut = None
+            with torch.cuda.stream(stream):
+                out = decs[0].run()
             for i in range(len(chunks)):
-                fut.result()
-                d = decs[i & 1]
-                fut = pool.submit(decs[(i + 1) & 1].prepare, chunks[i + 1]) if i + 1 < len(chunks) else None
-                with torch.cuda.stream(stream):
-                    out = d.run()
-                st = d.sync()
+                d, nxt = decs[i & 1], decs[(i + 1) & 1]
+                out_next = None
+                if i + 1 < len(chunks):
+                    # batch i+1 was prepared while batch i-1 ran (or just now, for i = 0)
+                    if i == 0:
+                        nxt.prepare(chunks[1])
+                    else:
+                        fut.result()
+                        fut = None
+                    with torch.cuda.stream(stream):
+                        out_next = nxt.run()
+                st = d.sync()                      # waits for batch i only (an event behind its last kernel)
+                if i + 2 < len(chunks):
+                    fut = pool.submit(d.prepare, chunks[i + 2])    # d is free again: its batch is done
                 yield out, st
+                out = out_next
         finally:
             if fut is not None:
                 try:

@@ -534,6 +534,52 @@ def test_double_buffered_stream_equals_batches(hip, oracle):
     d.close()
 
 
+def test_frames_in_page_locked_memory(hip, oracle):
+    """jpeg_hip_decoder_prepare_pinned: the frames go to the device in one DMA from the caller's buffer, at whatever
+    offsets they have there.  Same samples and statuses as the staged path -- whole stream and batches of odd
+    sizes, a frame with a stray marker that sync() has to cut (the caller's memory stays as it was), a broken
+    frame in the middle, a single frame, and one batch of 1, 2, 5 frames through mjpeg.decode_stream."""
+    from jpeg_amd import mjpeg
+    frames = []
+    for i in range(9):
+        img = synth_image(200, 120, 3, 8, seed=500 + i, frame=i)
+        err, j, _ = oracle.encode(img, P=8, H=2, V=2, q=55 + 4 * i, optimize=i % 2, restart_interval=(0, 5)[i % 2])
+        assert err == 0
+        frames.append(j)
+    j = frames[3]
+    marks = [k for k in range(len(j) - 1) if j[k] == 0xFF and 0xD0 <= j[k + 1] <= 0xD7]
+    at = marks[4] - 3
+    at += j[at - 1] == 0xFF
+    frames[3] = j[:at] + b"\xff\xe1\x00\x05abc" + j[at:]        # stray APP1, restart intervals behind it
+    frames[6] = frames[6][:40]                                # no frame header left: parse error
+    want = [oracle.decode(f) for f in frames]
+    pf = hip.PinnedFrames.from_frames(frames)
+    before = bytes(pf.buf.view())
+    for lo, hi in ((0, 9), (2, 5), (3, 4), (5, 9), (0, 1)):
+        d = hip.Decoder()
+        d.prepare(pf[lo:hi])
+        out = d.run()
+        st = d.sync()
+        px = d.to_arrays(out)
+        for k in range(lo, hi):
+            assert st[k - lo] == want[k][0], (lo, hi, k)
+            if want[k][0] == 0:
+                assert np.array_equal(px[k - lo], want[k][1]), (lo, hi, k)
+        # a second run of the same preparation (the cut frame is already cut)
+        out = d.run()
+        assert d.sync() == st
+        d.close()
+    assert bytes(pf.buf.view()) == before
+    good = hip.PinnedFrames.from_frames([f for k, f in enumerate(frames) if k != 6])
+    a = [(o.cpu().numpy().copy(), st) for o, st in mjpeg.decode_batches([f for k, f in enumerate(frames) if k != 6], batch=3)]
+    for batch in (3, 1, 8):
+        b = [(o.cpu().numpy().copy(), st) for o, st in mjpeg.decode_stream(good, batch=batch)]
+        assert np.array_equal(np.concatenate([o for o, _ in a]), np.concatenate([o for o, _ in b]))
+        assert sum((st for _, st in b), []) == [0] * 8
+    pf.buf.close()
+    good.buf.close()
+
+
 def test_markers_the_reference_rejects(hip, oracle):
     """APP9 / APP10 / APP15 / DNL end the reference's parse_format() with "unhandled marker"
     (decoder.c:654-656): the default is the same status; set_tolerant() skips such segments."""
