@@ -124,6 +124,94 @@ __device__ __forceinline__ unsigned block_excl_scan(unsigned v, unsigned *scratc
 	return base + inc - v;
 }
 
+// ---- sixteen bytes at a time (SWAR) ---------------------------------------------------------------
+// Threads whose 16 bytes, the byte before and the byte after all lie inside the frame -- all but two or
+// three per frame -- classify them four at a time in 32-bit words: a flag in bit 7 of every byte.
+
+__device__ __forceinline__ uint32_t swar_zero(uint32_t v)          // bit 7 of a byte set <=> the byte is 0x00 (exact)
+{
+	return ~(((v & 0x7f7f7f7fu) + 0x7f7f7f7fu) | v | 0x7f7f7f7fu);
+}
+
+__device__ __forceinline__ uint32_t flags_to_bits(uint32_t f)       // bits 7, 15, 23, 31 -> bits 0 .. 3
+{
+	return (((f >> 7) * 0x00204081u) >> 21) & 0xfu;
+}
+
+struct Cls16 {
+	uint32_t x[4];                    // the bytes (little endian words)
+	uint32_t kept, rst, term;         // bit i = byte i: payload / FF of RSTn / FF of another marker
+	uint32_t next;                    // the byte behind them
+};
+
+// fast: base > lo && base + 16 < hi (and base is a multiple of 16, so the words before and behind exist)
+__device__ __forceinline__ void classify16_fast(const uint8_t *raw, uint32_t base, Cls16 &c)
+{
+	const uint4 v = *reinterpret_cast<const uint4 *>(raw + base);
+	const uint32_t before = *reinterpret_cast<const uint32_t *>(raw + base - 4);
+	const uint32_t behind = *reinterpret_cast<const uint32_t *>(raw + base + 16);
+	c.x[0] = v.x;
+	c.x[1] = v.y;
+	c.x[2] = v.z;
+	c.x[3] = v.w;
+	c.next = behind & 0xffu;
+	uint32_t ff[5], z0[5], dn[5];
+	ff[0] = (before >> 24) == 0xffu ? 0x80000000u : 0u;             // only the byte before counts
+#pragma unroll
+	for (int i = 0; i < 4; ++i) {
+		ff[i + 1] = swar_zero(~c.x[i]);
+		z0[i] = swar_zero(c.x[i]);
+		dn[i] = swar_zero((c.x[i] & 0xf8f8f8f8u) ^ 0xd0d0d0d0u);
+	}
+	z0[4] = c.next == 0u ? 0x80u : 0u;                              // only the byte behind counts
+	dn[4] = (c.next & 0xf8u) == 0xd0u ? 0x80u : 0u;
+	uint32_t kept = 0, rst = 0, term = 0;
+#pragma unroll
+	for (int i = 0; i < 4; ++i) {
+		const uint32_t f = ff[i + 1];
+		const uint32_t n00 = __builtin_amdgcn_alignbit(z0[i + 1], z0[i], 8);     // the flags of every byte's successor
+		const uint32_t ndn = __builtin_amdgcn_alignbit(dn[i + 1], dn[i], 8);
+		const uint32_t pff = __builtin_amdgcn_alignbit(f, ff[i], 24);            // ... and of its predecessor
+		const uint32_t k = (f & n00) | (~f & ~(pff & (z0[i] | dn[i])) & 0x80808080u);
+		kept |= flags_to_bits(k) << (4 * i);
+		rst |= flags_to_bits(f & ndn) << (4 * i);
+		term |= flags_to_bits(f & ~(n00 | ndn)) << (4 * i);
+	}
+	c.kept = kept;
+	c.rst = rst;
+	c.term = term;
+}
+
+// any position: byte by byte, what lies outside [lo, hi) is neither kept nor a marker
+__device__ __forceinline__ void classify16_edge(const uint8_t *raw, uint32_t lo, uint32_t hi, uint32_t base, Cls16 &c)
+{
+	RawWindow win;
+	load_window(raw, lo, hi, base, win);
+	c.x[0] = c.x[1] = c.x[2] = c.x[3] = 0;
+	c.kept = c.rst = c.term = 0;
+	c.next = win.bytes[17];
+#pragma unroll
+	for (int i = 0; i < 16; ++i) {
+		const uint32_t p = base + i;
+		c.x[i >> 2] |= win.bytes[i + 1] << (8 * (i & 3));
+		if (p >= lo && p < hi) {
+			const unsigned cl = classify(win.bytes[i], win.bytes[i + 1], win.bytes[i + 2]);
+			c.kept |= (cl & 1u) << i;
+			c.rst |= ((cl >> 1) & 1u) << i;
+			c.term |= ((cl >> 2) & 1u) << i;
+		}
+	}
+}
+
+__device__ __forceinline__ void classify16(const uint8_t *raw, uint32_t lo, uint32_t hi, uint32_t base, Cls16 &c)
+{
+	if (base > lo && base + 16 < hi) {
+		classify16_fast(raw, base, c);
+	} else {
+		classify16_edge(raw, lo, hi, base, c);
+	}
+}
+
 __global__ __launch_bounds__(256) void k_ecs_scan(JhDecodeWork w)
 {
 	__shared__ unsigned scratch[4];
@@ -134,30 +222,15 @@ __global__ __launch_bounds__(256) void k_ecs_scan(JhDecodeWork w)
 	}
 	// chunks are aligned to absolute multiples of CHUNK_BYTES so that vector loads are aligned
 	const uint32_t base = (fr.raw_begin / CHUNK_BYTES + blockIdx.x) * CHUNK_BYTES + threadIdx.x * 16;
-	RawWindow win;
-	load_window(w.raw, fr.raw_begin, fr.raw_end, base, win);
-	unsigned kept = 0, rst = 0;
-	uint32_t term = 0xffffffffu;
-#pragma unroll
-	for (int i = 0; i < 16; ++i) {
-		const uint32_t p = base + i;
-		if (p >= fr.raw_begin && p < fr.raw_end) {
-			const unsigned cl = classify(win.bytes[i], win.bytes[i + 1], win.bytes[i + 2]);
-			kept += cl & 1u;
-			rst += (cl >> 1) & 1u;
-			if ((cl & 4u) && term == 0xffffffffu) {
-				term = p;
-			}
-		}
+	Cls16 c;
+	classify16(w.raw, fr.raw_begin, fr.raw_end, base, c);
+	if (c.term) {
+		atomicMin(&w.state[f].term_pos, base + (uint32_t)__ffs(c.term) - 1u);
 	}
-	if (term != 0xffffffffu) {
-		atomicMin(&w.state[f].term_pos, term);
-	}
-	const unsigned tk = block_reduce_add(kept, scratch);
-	const unsigned tr = block_reduce_add(rst, scratch);
+	const unsigned both = block_reduce_add((unsigned)__popc(c.kept) | (unsigned)__popc(c.rst) << 16, scratch);
 	if (threadIdx.x == 0) {
-		w.chunk_kept[fr.chunk_off + blockIdx.x] = tk;
-		w.chunk_rst[fr.chunk_off + blockIdx.x] = tr;
+		w.chunk_kept[fr.chunk_off + blockIdx.x] = both & 0xffffu;      // <= 4096 and <= 2048: no carry between the halves
+		w.chunk_rst[fr.chunk_off + blockIdx.x] = both >> 16;
 	}
 }
 
@@ -197,61 +270,102 @@ __global__ __launch_bounds__(256) void k_ecs_chunk_scan(JhDecodeWork w)
 	}
 }
 
+// The payload bytes of a chunk, packed.  A thread squeezes the bytes it drops (the 00 behind an FF, RSTn, what
+// lies behind the end of the data -- one or two in a sixteenth of the threads) out of its 16 bytes in
+// registers, ORs what is left into an LDS image of the chunk's output laid out like the destination modulo 16,
+// and the workgroup stores that image in whole aligned 16-byte pieces (the pieces it shares with the chunks
+// before and behind byte by byte).
 __global__ __launch_bounds__(256) void k_ecs_compact(JhDecodeWork w)
 {
 	__shared__ unsigned scratch[4];
+	__shared__ __align__(16) uint32_t obuf[CHUNK_BYTES / 4 + 8];
 	const int f = blockIdx.y;
 	const JhDecFrame fr = w.frames[f];
 	if (blockIdx.x >= fr.nchunk) {
 		return;
 	}
+	for (int i = threadIdx.x; i < CHUNK_BYTES / 4 + 8; i += 256) {
+		obuf[i] = 0;
+	}
 	JhDecState &st = w.state[f];
 	const uint32_t term = st.term_pos;
 	const uint32_t base = (fr.raw_begin / CHUNK_BYTES + blockIdx.x) * CHUNK_BYTES + threadIdx.x * 16;
-	RawWindow win;
-	load_window(w.raw, fr.raw_begin, fr.raw_end, base, win);
-	unsigned cls[16];
-	unsigned kept = 0, rst = 0;
-#pragma unroll
-	for (int i = 0; i < 16; ++i) {
-		const uint32_t p = base + i;
-		cls[i] = (p >= fr.raw_begin && p < fr.raw_end) ? classify(win.bytes[i], win.bytes[i + 1], win.bytes[i + 2]) : 0u;
-		kept += cls[i] & 1u;
-		rst += (cls[i] >> 1) & 1u;
+	Cls16 c;
+	classify16(w.raw, fr.raw_begin, fr.raw_end, base, c);
+	// nothing counts from the terminating marker on
+	const uint32_t live = term <= base ? 0u : (term - base >= 16u ? 0xffffu : (1u << (term - base)) - 1u);
+	const uint32_t kept = c.kept & live, rst = c.rst & live;
+	const unsigned nk = (unsigned)__popc(kept);
+	unsigned total;
+	const unsigned excl = block_excl_scan(nk | (unsigned)__popc(rst) << 16, scratch, &total);   // ends with a barrier: obuf is zero
+	const uint32_t ok0 = w.chunk_kept[fr.chunk_off + blockIdx.x];
+	const uint32_t ok = ok0 + (excl & 0xffffu);
+	const uint32_t orr = w.chunk_rst[fr.chunk_off + blockIdx.x] + (excl >> 16);
+
+	if (term >= base && term < base + 16u && term < fr.raw_end) {
+		// the marker that ends the entropy-coded data: everything before it has been counted
+		const uint32_t i = term - base;
+		st.term_marker = i == 15u ? c.next : (c.x[(i + 1) >> 2] >> (8 * ((i + 1) & 3))) & 0xffu;
+		st.cs_len = ok + nk;
+		const uint32_t sg = orr + (uint32_t)__popc(rst) + 1u;
+		st.nseg = sg;
+		if (sg < fr.seg_cap) {
+			w.seg_start[fr.seg_off + sg] = ok + nk;
+		} else {
+			atomicOr(&st.status, JH_ST_SEG_OVERFLOW);
+		}
 	}
-	unsigned tk, tr;
-	unsigned ok = w.chunk_kept[fr.chunk_off + blockIdx.x] + block_excl_scan(kept, scratch, &tk);
-	unsigned orr = w.chunk_rst[fr.chunk_off + blockIdx.x] + block_excl_scan(rst, scratch, &tr);
-	uint8_t *cs = w.cs + fr.cs_off;
-#pragma unroll
-	for (int i = 0; i < 16; ++i) {
-		const uint32_t p = base + i;
-		if (p == term && p < fr.raw_end) {
-			// the marker that ends the entropy-coded data: everything before it has been counted
-			st.term_marker = win.bytes[i + 2];
-			st.cs_len = ok;
-			st.nseg = orr + 1;
-			if (orr + 1 < fr.seg_cap) {
-				w.seg_start[fr.seg_off + orr + 1] = ok;
-			} else {
-				atomicOr(&st.status, JH_ST_SEG_OVERFLOW);
+	for (uint32_t m = rst, n = 1; m; m &= m - 1u, ++n) {
+		// segment (orr + n) starts at the payload byte that follows this marker
+		const uint32_t i = (uint32_t)__ffs(m) - 1u;
+		if (orr + n < fr.seg_cap) {
+			w.seg_start[fr.seg_off + orr + n] = ok + (uint32_t)__popc(kept & ((1u << i) - 1u));
+		} else {
+			atomicOr(&st.status, JH_ST_SEG_OVERFLOW);
+		}
+	}
+	if (nk) {
+		uint32_t x0 = c.x[0], x1 = c.x[1], x2 = c.x[2], x3 = c.x[3];
+		for (uint32_t drop = ~kept & 0xffffu; drop;) {
+			// squeeze out the highest dropped byte: everything above it moves down, a zero comes in at the top
+			const uint32_t p = 31u - (uint32_t)__clz(drop);
+			drop &= ~(1u << p);
+			const uint32_t d = p >> 2, below = (1u << (8u * (p & 3u))) - 1u;
+			const uint32_t s0 = __builtin_amdgcn_alignbit(x1, x0, 8), s1 = __builtin_amdgcn_alignbit(x2, x1, 8);
+			const uint32_t s2 = __builtin_amdgcn_alignbit(x3, x2, 8), s3 = x3 >> 8;
+			const uint32_t m0 = d == 0 ? below : 0xffffffffu;
+			const uint32_t m1 = d < 1 ? 0u : (d == 1 ? below : 0xffffffffu);
+			const uint32_t m2 = d < 2 ? 0u : (d == 2 ? below : 0xffffffffu);
+			const uint32_t m3 = d < 3 ? 0u : below;
+			x0 = (x0 & m0) | (s0 & ~m0);
+			x1 = (x1 & m1) | (s1 & ~m1);
+			x2 = (x2 & m2) | (s2 & ~m2);
+			x3 = (x3 & m3) | (s3 & ~m3);
+		}
+		// into the image: byte q of it is byte (ok0 & ~15) + q of the frame's stream
+		const uint32_t q = (ok0 & 15u) + (excl & 0xffffu);
+		const uint32_t sh = 8u * (q & 3u);
+		uint32_t *dst = obuf + (q >> 2);
+		atomicOr(dst + 0, x0 << sh);
+		atomicOr(dst + 1, (uint32_t)((((unsigned long long)x1 << 32 | x0) << sh) >> 32));
+		atomicOr(dst + 2, (uint32_t)((((unsigned long long)x2 << 32 | x1) << sh) >> 32));
+		atomicOr(dst + 3, (uint32_t)((((unsigned long long)x3 << 32 | x2) << sh) >> 32));
+		atomicOr(dst + 4, (uint32_t)(((unsigned long long)x3 << sh) >> 32));
+	}
+	__syncthreads();
+	const uint32_t nkept = total & 0xffffu;
+	const uint32_t lead = ok0 & 15u;
+	uint8_t *out = w.cs + fr.cs_off + (ok0 - lead);                // 16-byte aligned (cs_off is a multiple of 64)
+	for (uint32_t g = threadIdx.x; g * 16u < lead + nkept; g += 256) {
+		const uint32_t a = g * 16u < lead ? lead - g * 16u : 0u;    // this chunk's bytes in the piece: [a, b)
+		const uint32_t b = min(16u, lead + nkept - g * 16u);
+		if (a == 0 && b == 16u) {
+			*reinterpret_cast<uint4 *>(out + g * 16u) = *reinterpret_cast<const uint4 *>(obuf + g * 4u);
+		} else {
+			for (uint32_t j = a; j < b; ++j) {
+				out[g * 16u + j] = (uint8_t)(obuf[g * 4u + (j >> 2)] >> (8u * (j & 3u)));
 			}
 		}
-		if (p < term) {
-			if (cls[i] & 1u) {
-				cs[ok] = (uint8_t)win.bytes[i + 1];
-			}
-			if (cls[i] & 2u) {
-				// segment (orr + 1) starts at the payload byte that follows this marker
-				if (orr + 1 < fr.seg_cap) {
-					w.seg_start[fr.seg_off + orr + 1] = ok;
-				} else {
-					atomicOr(&st.status, JH_ST_SEG_OVERFLOW);
-				}
-			}
-		}
-		ok += cls[i] & 1u;
-		orr += (cls[i] >> 1) & 1u;
 	}
 }
 
