@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libjpeg_amd.so")
+LIB_PATH = os.environ.get("JPEG_AMD_LIB") or os.path.join(HERE, "libjpeg_amd.so")   # the override is for experiments (tools/)
 
 RET_SUCCESS = 0
 RET_FAILURE_FILE_IO = 0x1000

@@ -252,36 +252,196 @@ __device__ __forceinline__ void store_agg(JhWgAgg *dst, const Agg &t, uint32_t e
 }
 
 // =================================================================================== chains
+//
+// Four kernels.  k_huff_chains: steps 0 and 1 of every chain, one thread per chain, no exchange between threads
+// (dense waves, tables and DC sums are all the LDS it needs).  k_huff_links: which chains coincide with their
+// younger neighbour after step 1 (nine in ten), which ran into garbage, which go on -- those are listed.
+// k_huff_survivors: one thread per listed chain walks on, up to JH_CHAIN_MAX steps, comparing its exit state of
+// every sub-sequence jl with the two states steps 0 and 1 left there (chain jl's own, chain jl-1's); dense
+// waves again.  k_huff_emit: the path of every workgroup range and its records.
+// (One kernel did all of this before, with the survivors' steps as sparse rounds between workgroup barriers:
+// those rounds took 29 % of its time for an eighth of the work, while the LDS of the whole workgroup stayed taken.)
+
+// the chain ran off the end of the data (no code matched, no restart segment left) before the stream was over
+__device__ __forceinline__ bool rec_garbage(const JhSubInfo &r, uint32_t total_bits, uint32_t next_sub, uint32_t nsub)
+{
+	return (uint32_t)(r.state & 0xffffffffu) >= total_bits && next_sub < nsub;
+}
 
 __global__ __launch_bounds__(256) void k_huff_chains(const HuffArgs a)
 {
 	extern __shared__ __align__(16) unsigned char smem[];
 	unsigned char *luts = smem;
 	__shared__ DecTables tb;
-	// LDS decides how many workgroups share a CU, and this kernel's time follows the number of waves in flight
-	// (measured: 12 instead of 16 waves per CU cost 21 %): the arrays of the chain steps and the path records of
-	// the emission, which never live at the same time, share one piece of it.  29 KB with four tables: 5
-	// workgroups = 20 waves per CU.
-	enum {
-		OFF_DCS = 0,                                       // int [JH_MAX_COMP][256]
-		OFF_DKEY = OFF_DCS + JH_MAX_COMP * 256 * 4,        // u64 [256][DIRN]
-		OFF_DOWNER = OFF_DKEY + 256 * DIRN * 8,            // u16 [256][DIRN]
-		OFF_CSTATE = OFF_DOWNER + 256 * DIRN * 2,          // u64 [256]
-		OFF_CSEG = OFF_CSTATE + 256 * 8,                   // u32 [256]
-		OFF_ALIVE = OFF_CSEG + 256 * 4,                    // u16 [2][256]
-		OFF_DCNT = OFF_ALIVE + 2 * 256 * 2,                // u8 [256]
-		STEP_BYTES = OFF_DCNT + 256,
-		WORK_BYTES = STEP_BYTES > (int)sizeof(PathWork) ? STEP_BYTES : (int)sizeof(PathWork)
-	};
-	__shared__ __align__(16) unsigned char work[WORK_BYTES];
-	int (*dcs)[256] = reinterpret_cast<int (*)[256]>(work + OFF_DCS);
-	unsigned long long (*dkey)[DIRN] = reinterpret_cast<unsigned long long (*)[DIRN]>(work + OFF_DKEY);
-	uint16_t (*downer)[DIRN] = reinterpret_cast<uint16_t (*)[DIRN]>(work + OFF_DOWNER);
-	unsigned long long *cstate = reinterpret_cast<unsigned long long *>(work + OFF_CSTATE);
-	uint32_t *cseg = reinterpret_cast<uint32_t *>(work + OFF_CSEG);
-	uint16_t (*alive)[256] = reinterpret_cast<uint16_t (*)[256]>(work + OFF_ALIVE);
-	uint8_t *dcnt = work + OFF_DCNT;
-	__shared__ int nalive[2];
+	__shared__ int dcs[JH_MAX_COMP][256];
+
+	const JhDecodeWork &w = a.w;
+	const int f = blockIdx.y;
+	const JhDecFrame fr = w.frames[f];
+	const JhDecState fs = w.state[f];
+	const uint32_t total_bits = fs.cs_len * 8u;
+	const uint32_t nsub = (total_bits + JH_SUBSEQ_BITS - 1) / JH_SUBSEQ_BITS;
+	if (blockIdx.x * 256u >= nsub) {
+		return;
+	}
+	load_tables(w, fr, luts, &tb, a.g, 256);              // ends with a barrier, the only one
+	const int tid = threadIdx.x;
+	const uint32_t t = blockIdx.x * 256u + tid;
+	if (t >= nsub) {
+		return;
+	}
+	const uint8_t *cs = w.cs + fr.cs_off;
+	const uint32_t *seg_start = w.seg_start + fr.seg_off;
+	const uint32_t nseg = min(fs.nseg, fr.seg_cap - 1);
+	JhSubInfo *rec = w.rec + (size_t)(fr.sub_off + t) * (KMAX + 1);
+	const RegStream S{cs};
+	int *mydcs = &dcs[0][tid];
+
+	// step 0: the chain's own sub-sequence, from the guess
+	DecState st;
+	state_from(st, (unsigned long long)t * JH_SUBSEQ_BITS, 0);
+	st.seg = nseg > 1 ? find_segment(seg_start, nseg, st.pos >> 3) : 0u;
+	decode_span<false>(st, (t + 1) * JH_SUBSEQ_BITS, S, total_bits, seg_start, nseg, luts, tb, a.g.B, mydcs, 256, nullptr, 0, 0);
+	store_info(&rec[0], st);
+	if (st.pos >= total_bits || t + 1 >= nsub) {
+		return;                            // garbage (k_huff_links restarts with the next chain's guess), or the last one
+	}
+	// step 1: the next sub-sequence from where step 0 ended (sums counted anew)
+	const unsigned long long ps = pack_state(st);
+	const uint32_t sg = st.seg;
+	state_from(st, ps, sg);
+	decode_span<false>(st, (t + 2) * JH_SUBSEQ_BITS, S, total_bits, seg_start, nseg, luts, tb, a.g.B, mydcs, 256, nullptr, 0, 0);
+	store_info(&rec[1], st);
+}
+
+__global__ __launch_bounds__(256) void k_huff_links(const HuffArgs a)
+{
+	const JhDecodeWork &w = a.w;
+	const int f = blockIdx.y;
+	const JhDecFrame fr = w.frames[f];
+	const JhDecState fs = w.state[f];
+	const uint32_t total_bits = fs.cs_len * 8u;
+	const uint32_t nsub = (total_bits + JH_SUBSEQ_BITS - 1) / JH_SUBSEQ_BITS;
+	const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+	if (blockIdx.x * 256u >= nsub) {
+		return;
+	}
+	bool survive = false;
+	if (t < nsub) {
+		const JhSubInfo *rec = w.rec + (size_t)(fr.sub_off + t) * (KMAX + 1);
+		const JhSubInfo r0 = rec[0];
+		uint32_t meta;                     // steps walked | link distance << 8 | restart link
+		if (rec_garbage(r0, total_bits, t + 1, nsub)) {
+			meta = 0u | (1u << 8) | META_RESTART;
+		} else if (t + 1 >= nsub) {
+			meta = 0u;
+		} else {
+			const JhSubInfo r1 = rec[1];
+			const JhSubInfo n0 = rec[KMAX + 1];            // the younger neighbour after its step 0
+			if (rec_garbage(r1, total_bits, t + 2, nsub)) {
+				meta = 1u | (2u << 8) | META_RESTART;
+			} else if (!rec_garbage(n0, total_bits, t + 2, nsub) && chain_key(r1.state, r1.seg) == chain_key(n0.state, n0.seg)) {
+				meta = 1u | (1u << 8);                     // same state as the younger chain: identical from here on
+			} else {
+				meta = 1u;
+				survive = KMAX > 1 && t + 2 < nsub;
+			}
+		}
+		w.meta[fr.sub_off + t] = meta;     // a survivor's is written again when it stops
+	}
+	const unsigned long long m = __ballot(survive);
+	if (m) {
+		const int lane = threadIdx.x & 63;
+		uint32_t base = 0;
+		if (lane == (int)__ffsll((long long)m) - 1) {
+			base = atomicAdd(&w.state[f].nsurv, (uint32_t)__popcll(m));
+		}
+		base = __shfl(base, (int)__ffsll((long long)m) - 1, 64);
+		if (survive) {
+			w.surv[fr.sub_off + base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = t;
+		}
+	}
+}
+
+__global__ __launch_bounds__(256) void k_huff_survivors(const HuffArgs a)
+{
+	extern __shared__ __align__(16) unsigned char smem[];
+	unsigned char *luts = smem;
+	__shared__ DecTables tb;
+	__shared__ int dcs[JH_MAX_COMP][256];
+
+	const JhDecodeWork &w = a.w;
+	const int f = blockIdx.y;
+	const JhDecFrame fr = w.frames[f];
+	const JhDecState fs = w.state[f];
+	const uint32_t nsurv = fs.nsurv;
+	if (blockIdx.x * 256u >= nsurv) {
+		return;
+	}
+	const uint32_t total_bits = fs.cs_len * 8u;
+	const uint32_t nsub = (total_bits + JH_SUBSEQ_BITS - 1) / JH_SUBSEQ_BITS;
+	load_tables(w, fr, luts, &tb, a.g, 256);
+	const int tid = threadIdx.x;
+	if (blockIdx.x * 256u + tid >= nsurv) {
+		return;
+	}
+	const uint32_t i = w.surv[fr.sub_off + blockIdx.x * 256u + tid];
+	const uint8_t *cs = w.cs + fr.cs_off;
+	const uint32_t *seg_start = w.seg_start + fr.seg_off;
+	const uint32_t nseg = min(fs.nseg, fr.seg_cap - 1);
+	JhSubInfo *rec = w.rec + (size_t)(fr.sub_off + i) * (KMAX + 1);
+	const RegStream S{cs};
+	int *mydcs = &dcs[0][tid];
+
+	unsigned long long ps = rec[1].state;
+	uint32_t sg = rec[1].seg;
+	uint32_t meta = 1u;
+	for (uint32_t d = 2; d <= KMAX; ++d) {
+		const uint32_t jl = i + d;         // < nsub
+		DecState st;
+		state_from(st, ps, sg);
+		decode_span<false>(st, (jl + 1) * JH_SUBSEQ_BITS, S, total_bits, seg_start, nseg, luts, tb, a.g.B, mydcs, 256, nullptr, 0, 0);
+		store_info(&rec[d], st);
+		meta = d;
+		if (st.pos >= total_bits && jl + 1 < nsub) {
+			meta |= ((d + 1u) << 8) | META_RESTART;        // garbage: restart with the next chain's guess
+			break;
+		}
+		ps = pack_state(st);
+		sg = st.seg;
+		const unsigned long long key = chain_key(ps, sg);
+		// Younger chains that were here in steps 0 and 1: chain jl (its own sub-sequence) and chain jl - 1.  Equal
+		// state = identical future.  Either of them has the record of sub-sequence jl + 1 if there is one: chain
+		// jl from its step 1; chain jl - 1, which did not coincide with chain jl or this chain would too, as a survivor.
+		const JhSubInfo *rj = w.rec + (size_t)(fr.sub_off + jl) * (KMAX + 1);
+		const JhSubInfo o0 = rj[0];
+		const JhSubInfo p0 = (rj - (KMAX + 1))[0];
+		uint32_t hit = 0;
+		if (!rec_garbage(p0, total_bits, jl, nsub)) {
+			const JhSubInfo p1 = (rj - (KMAX + 1))[1];
+			if (!rec_garbage(p1, total_bits, jl + 1, nsub) && chain_key(p1.state, p1.seg) == key) {
+				hit = d - 1u;
+			}
+		}
+		if (!rec_garbage(o0, total_bits, jl + 1, nsub) && chain_key(o0.state, o0.seg) == key) {
+			hit = d;
+		}
+		if (hit) {
+			meta |= hit << 8;
+			break;
+		}
+		if (jl + 1 >= nsub) {
+			break;
+		}
+	}
+	w.meta[fr.sub_off + i] = meta;
+}
+
+// One workgroup per range of JH_SEQ_OWN own + JH_CHAIN_MAX ghost sub-sequences: the path from the range's first
+// chain through the links, and the records along it.
+__global__ __launch_bounds__(256) void k_huff_emit(const HuffArgs a)
+{
+	__shared__ __align__(16) PathWork W;
 	__shared__ PathLds P;
 
 	const JhDecodeWork &w = a.w;
@@ -295,130 +455,31 @@ __global__ __launch_bounds__(256) void k_huff_chains(const HuffArgs a)
 		return;
 	}
 	const uint32_t j0 = b * (uint32_t)OWN;
-	load_tables(w, fr, luts, &tb, a.g, 256);
-
-	const uint8_t *cs = w.cs + fr.cs_off;
-	const uint32_t *seg_start = w.seg_start + fr.seg_off;
-	const uint32_t nseg = min(fs.nseg, fr.seg_cap - 1);
 	const int tid = threadIdx.x;
 	const int range_len = (int)min(256u, nsub - j0);      // own + ghost sub-sequences of this workgroup
-	JhSubInfo *rec = w.rec + (size_t)(fr.sub_off + j0) * (KMAX + 1);
-	const RegStream S{cs};
-	int *mydcs = &dcs[0][tid];
+	const JhSubInfo *rec = w.rec + (size_t)(fr.sub_off + j0) * (KMAX + 1);
 
-	// ---- step 0: every chain decodes its own sub-sequence -------------------------------------
-	if (tid < 2) {
-		nalive[tid] = 0;
-	}
-	dcnt[tid] = 0;
-	P.nst[tid] = 0;
-	P.dflag[tid] = 0;
-	P.succ[tid] = NONE16;
-	__syncthreads();
+	// links inside the range (a chain that leaves it has none here: the next range sees it whole)
 	{
-		bool keep = false;
+		uint32_t nst = 0, link = 0, flag = 0;
 		if (tid < range_len) {
-			DecState st;
-			const uint32_t t = j0 + tid;
-			state_from(st, (unsigned long long)t * JH_SUBSEQ_BITS, 0);
-			st.seg = nseg > 1 ? find_segment(seg_start, nseg, st.pos >> 3) : 0u;
-			decode_span<false>(st, (t + 1) * JH_SUBSEQ_BITS, S, total_bits, seg_start, nseg, luts, tb, a.g.B, mydcs, 256, nullptr, 0, 0);
-			// identical bytes are written by the neighbour workgroup for the chains both of them walk
-			store_info(&rec[(size_t)tid * (KMAX + 1)], st);
-			const bool more = tid + 1 < range_len;
-			if (st.pos >= total_bits && t + 1 < nsub) {
-				// garbage: restart with the next chain's guess
-				if (more) {
-					P.succ[tid] = (uint16_t)(tid + 1);
-					P.dflag[tid] = 1;
-				}
-			} else {
-				const unsigned long long ps = pack_state(st);
-				dkey[tid][0] = chain_key(ps, st.seg);
-				downer[tid][0] = (uint16_t)tid;
-				dcnt[tid] = 1;
-				cstate[tid] = ps;
-				cseg[tid] = st.seg;
-				keep = more;
-			}
+			const uint32_t m = w.meta[fr.sub_off + j0 + tid];
+			nst = m & 0xffu;
+			link = (m >> 8) & 0xffu;
+			flag = m & META_RESTART;
 		}
-		compact_append(keep, (uint16_t)tid, alive[0], &nalive[0]);
-	}
-
-	// ---- steps 1..KMAX: chains walk on until they coincide with a younger chain -----------------
-	int cur = 0;
-	for (int d = 1; d <= KMAX; ++d) {
-		__syncthreads();
-		const int n = nalive[cur];
-		if (n == 0) {
-			break;
-		}
-		__syncthreads();
-		if (tid == 0) {
-			nalive[cur ^ 1] = 0;
-		}
-		__syncthreads();
-		bool keep = false;
-		int i = 0;
-		if (tid < n) {
-			i = alive[cur][tid];
-			const int jl = i + d;
-			DecState st;
-			state_from(st, cstate[i], cseg[i]);
-			decode_span<false>(st, (j0 + jl + 1) * JH_SUBSEQ_BITS, S, total_bits, seg_start, nseg, luts, tb, a.g.B, mydcs, 256, nullptr, 0, 0);
-			store_info(&rec[(size_t)i * (KMAX + 1) + d], st);
-			P.nst[i] = (uint8_t)d;
-			const bool more = jl + 1 < range_len;
-			if (st.pos >= total_bits && j0 + jl + 1 < nsub) {
-				if (more) {
-					P.succ[i] = (uint16_t)(jl + 1);
-					P.dflag[i] = 1;
-				}
-			} else {
-				const unsigned long long ps = pack_state(st);
-				const unsigned long long key = chain_key(ps, st.seg);
-				const int cnt = dcnt[jl];
-				int hit = -1;
-				for (int e = 0; e < cnt; ++e) {
-					if (dkey[jl][e] == key) {
-						hit = downer[jl][e];
-					}
-				}
-				if (hit >= 0) {
-					P.succ[i] = (uint16_t)hit;       // same state as a younger chain: identical from here on
-				} else {
-					if (cnt < DIRN) {
-						dkey[jl][cnt] = key;
-						downer[jl][cnt] = (uint16_t)i;
-						dcnt[jl] = (uint8_t)(cnt + 1);
-					}
-					if (d < KMAX && more) {
-						keep = true;
-						cstate[i] = ps;
-						cseg[i] = st.seg;
-					}
-				}
-			}
-		}
-		compact_append(keep, (uint16_t)i, alive[cur ^ 1], &nalive[cur ^ 1]);
-		cur ^= 1;
-	}
-	__syncthreads();
-
-	// ---- links of the own chains (for the walk kernels) ----------------------------------------------
-	const bool need_next = b + 1 < jh_num_chain_wgs(nsub);
-	if ((tid < OWN || !need_next) && tid < range_len) {
-		const uint32_t link = P.succ[tid] != NONE16 ? (uint32_t)(P.succ[tid] - tid) : 0u;
-		w.meta[fr.sub_off + j0 + tid] = (uint32_t)P.nst[tid] | (link << 8) | (P.dflag[tid] ? META_RESTART : 0u);
+		P.nst[tid] = (uint8_t)nst;
+		P.succ[tid] = (link != 0 && tid + (int)link < range_len) ? (uint16_t)(tid + link) : (uint16_t)NONE16;
+		P.dflag[tid] = flag ? 1 : 0;
 	}
 
 	// ---- emit from the path of the first chain ---------------------------------------------------
-	PathWork &W = *reinterpret_cast<PathWork *>(work);      // the arrays of the chain steps are dead from here on
 	const int lo = b == 0 ? 0 : KMAX, hi = range_len - 1;
 	if (tid == 0) {
 		P.gap = 0;
 	}
 	W.cov[tid] = 0;
+	__syncthreads();
 	mark_path(P, W, 0, lo - 1);
 	if (W.mark[tid] && tid < range_len) {
 		const int from = tid == 0 ? 0 : (int)W.pred[tid] + (int)P.nst[W.pred[tid]] + 1;
@@ -510,6 +571,9 @@ __device__ __forceinline__ JhSubInfo walk_step(const WalkCtx &c, unsigned long l
 		return R;
 	}
 	const unsigned long long keyT = chain_key(T, Tseg);
+	if (r != 0xffffffffu && q - r > (c.meta[r] & 0xffu)) {
+		r = 0xffffffffu;                   // the chain that was being followed has no record of this sub-sequence
+	}
 	if (r == 0xffffffffu) {
 		// a stored chain that ENTERS q in the true state?  chain q itself (lane 0) or an older one (lane d)
 		bool hit = false;
@@ -905,15 +969,19 @@ int jh_launch_huff_sync(const JhDecodeWork &w, const JhGeom &g, hipStream_t s, c
 	a.g = g;
 	a.round = 0;
 	const size_t lds = sizeof(JhHuffLut) * (size_t)w.max_luts;
-	const size_t lds_chains = lds;
 	const unsigned nwg = jh_num_chain_wgs(w.max_subs);
-	// static + dynamic LDS of this kernel exceeds the 64 KB default limit
-	if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_huff_chains), hipFuncAttributeMaxDynamicSharedMemorySize,
-	                        (int)lds_chains) != hipSuccess) {
-		return -1;
-	}
+	const unsigned nblk = (w.max_subs + 255u) / 256u;
 	JH_T_BEGIN(th, "k_huff_chains", s);
-	hipLaunchKernelGGL(k_huff_chains, dim3(nwg, w.nframes), dim3(256), lds_chains, s, a);
+	hipLaunchKernelGGL(k_huff_chains, dim3(nblk, w.nframes), dim3(256), lds, s, a);
+	JH_T_END(th, s);
+	JH_T_BEGIN(th, "k_huff_links", s);
+	hipLaunchKernelGGL(k_huff_links, dim3(nblk, w.nframes), dim3(256), 0, s, a);
+	JH_T_END(th, s);
+	JH_T_BEGIN(th, "k_huff_survivors", s);
+	hipLaunchKernelGGL(k_huff_survivors, dim3(nblk, w.nframes), dim3(256), lds, s, a);
+	JH_T_END(th, s);
+	JH_T_BEGIN(th, "k_huff_emit", s);
+	hipLaunchKernelGGL(k_huff_emit, dim3(nwg, w.nframes), dim3(256), 0, s, a);
 	JH_T_END(th, s);
 	JH_T_BEGIN(th, "k_huff_walk", s);
 	for (int round = 0; round < JH_WALK_ROUNDS; ++round) {

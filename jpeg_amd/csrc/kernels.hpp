@@ -48,6 +48,7 @@ struct JhDecState {               // written by the device
 	                              // inconsistent after the walk rounds, 4 a walk had to decode too much by itself, 16 test hook
 	uint32_t term_marker;         // second byte of the marker at term_pos (0xd9 = EOI)
 	uint32_t ndrop;               // restart segments that ended inside an MCU (k_huff_fixup has work)
+	uint32_t nsurv;               // chains that walk on after step 1 (k_huff_links -> k_huff_survivors)
 	uint32_t ntail;               // the LAST segment ended inside an MCU: blocks below this index hold what the
 	                              // reference leaves of it (decoder.c:347-355) and are not cleared
 };
@@ -76,6 +77,7 @@ struct JhDecodeWork {             // device pointers of one decoder batch
 	uint32_t *chunk_kept, *chunk_rst;
 	JhSubInfo *rec;               // [sub-sequence t][step d <= JH_CHAIN_MAX]: chain t after sub-sequence t + d
 	uint32_t *meta;               // per chain: steps walked | (link distance << 8) | restarted-after-garbage << 31
+	uint32_t *surv;               // per frame (at sub_off): the chains listed by k_huff_links
 	JhSubInfo *prec;              // per sub-sequence: its record on the emitting workgroup's path (bit 63 of state: none)
 	unsigned long long *wg_key;   // per chains workgroup: the entry state its emitted records assume
 	JhWgAgg *wg_agg;              // per chains workgroup: totals of its emitted range, flags

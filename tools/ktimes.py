@@ -20,6 +20,7 @@ def main():
     enc, samples, jpgs, cfg = bench.make_batch(torch, binding, synth, name, F, 0)
     dec = binding.Decoder(0)
     dec.prepare(jpgs)
+    dec.set_debug(int(os.environ.get("KT_DEBUG", "0")))
     out = dec.alloc_output()
     for _ in range(2):
         dec.run(out)
