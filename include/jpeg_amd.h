@@ -145,6 +145,9 @@ int  jpeg_hip_decoder_get_timing(jpeg_hip_decoder *dec, const char **names, floa
  * set_debug: bit 0 forces the repair path on every other workgroup, bit 1 forces the serial walk
  * (tests: all three paths must give identical results). */
 int  jpeg_hip_decoder_get_stats(const jpeg_hip_decoder *dec, int frame, uint32_t stats[4]);
+/* Diagnostics (after sync): how many chains of the frame's first scan walked 0, 1, 2 ... further sub-sequences
+ * before they fell in with a younger one (hist[cap - 1] collects the rest).  No counterpart in the reference. */
+int  jpeg_hip_decoder_get_chain_steps(jpeg_hip_decoder *dec, int frame, uint32_t *hist, int cap);
 void jpeg_hip_decoder_set_debug(jpeg_hip_decoder *dec, int flags);
 /* parse_format() (decoder.c:472-659) ends in "unhandled marker" -> RET_FAILURE_FILE_UNSUPPORTED on APP9,
  * APP10, APP15, DNL and JPGn segments (decoder.c:654-656); prepare() does the same by default.  on != 0

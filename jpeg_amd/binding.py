@@ -31,7 +31,7 @@ EXPORTS = [
     "jpeg_hip_decoder_info", "jpeg_hip_decoder_frame_bytes", "jpeg_hip_decoder_run",
     "jpeg_hip_decoder_sync", "jpeg_hip_decoder_get_coefficients", "jpeg_hip_decoder_set_timing",
     "jpeg_hip_decoder_get_timing", "jpeg_hip_decoder_ecs_bytes", "jpeg_hip_decoder_get_stats",
-    "jpeg_hip_decoder_set_debug", "jpeg_hip_decoder_set_tolerant", "jpeg_hip_mjpeg_split",
+    "jpeg_hip_decoder_set_debug", "jpeg_hip_decoder_get_chain_steps", "jpeg_hip_decoder_set_tolerant", "jpeg_hip_mjpeg_split",
     "jpeg_hip_encoder_create", "jpeg_hip_encoder_destroy", "jpeg_hip_encoder_configure",
     "jpeg_hip_encoder_info", "jpeg_hip_encoder_run", "jpeg_hip_encoder_sync",
     "jpeg_hip_encoder_get_jpeg", "jpeg_hip_encoder_device_jpeg", "jpeg_hip_encoder_get_coefficients",
@@ -331,6 +331,14 @@ class Decoder:
         if err:
             raise JpegError(err, "jpeg_hip_decoder_get_stats")
         return tuple(int(v) for v in out)
+
+    def chain_steps(self, frame=0, cap=18):
+        """diagnostics: chains by the number of further sub-sequences they walked"""
+        h = (C.c_uint32 * cap)()
+        err = self.L.jpeg_hip_decoder_get_chain_steps(self.h, frame, h, cap)
+        if err:
+            raise JpegError(err, "jpeg_hip_decoder_get_chain_steps")
+        return list(h)
 
     def set_debug(self, flags):
         self.L.jpeg_hip_decoder_set_debug(self.h, int(flags))

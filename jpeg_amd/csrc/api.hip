@@ -1178,6 +1178,28 @@ extern "C" int jpeg_hip_decoder_get_stats(const jpeg_hip_decoder *dec, int frame
 	return RET_SUCCESS;
 }
 
+extern "C" int jpeg_hip_decoder_get_chain_steps(jpeg_hip_decoder *dec, int frame, uint32_t *hist, int cap)
+{
+	if (!dec || !dec->ran || frame < 0 || frame >= dec->nframes || !hist || cap <= 0 || dec->pass.empty()) {
+		return RET_FAILURE_LOGIC_ERROR;
+	}
+	HIPCHK(hipSetDevice(dec->device));
+	const DecPass &ps = dec->pass[0];
+	const uint32_t nsub = (ps.state[frame].cs_len * 8u + JH_SUBSEQ_BITS - 1) / JH_SUBSEQ_BITS;
+	std::vector<uint32_t> meta(nsub);
+	if (nsub) {
+		HIPCHK(hipMemcpy(meta.data(), ps.d_meta + ps.frames[frame].sub_off, nsub * sizeof(uint32_t), hipMemcpyDeviceToHost));
+	}
+	for (int i = 0; i < cap; ++i) {
+		hist[i] = 0;
+	}
+	for (uint32_t m : meta) {
+		const int steps = (int)(m & 0xffu);
+		hist[steps < cap ? steps : cap - 1]++;
+	}
+	return RET_SUCCESS;
+}
+
 extern "C" void jpeg_hip_decoder_set_debug(jpeg_hip_decoder *dec, int flags)
 {
 	dec->debug = flags;

@@ -21,8 +21,8 @@ struct DecTables {                    // workgroup-shared decode context (LDS)
 	// per block of the MCU: (DC table offset / 16) | (AC table offset / 16) << 12 | component << 24
 	uint32_t info[JH_MAX_MCU_BLOCKS];
 	// the same, unpacked for the hot loop (one 16-byte read): x = byte offset of the DC table inside the
-	// LDS copy, y = of the AC table, z = byte offset of the component's DC accumulator relative to the
-	// thread's first one, w = the block that follows in the MCU
+	// LDS copy, y = of the AC table, z = component * zunit (load_tables: the byte offset of the component's DC
+	// accumulator relative to the thread's first one, or the component itself), w = the block that follows in the MCU
 	uint4 ent[JH_MAX_MCU_BLOCKS];
 };
 
@@ -341,7 +341,7 @@ __device__ __forceinline__ uint32_t find_segment(const uint32_t *seg_start, uint
 }
 
 __device__ __forceinline__ void load_tables(const JhDecodeWork &w, const JhDecFrame &fr, unsigned char *luts, DecTables *tb,
-                                            const JhGeom &g, int dcs_stride)
+                                            const JhGeom &g, int zunit)
 {
 	const uint32_t *src = reinterpret_cast<const uint32_t *>(w.luts + fr.lut_off);
 	uint32_t *dst = reinterpret_cast<uint32_t *>(luts);
@@ -357,7 +357,7 @@ __device__ __forceinline__ void load_tables(const JhDecodeWork &w, const JhDecFr
 		                        (uint32_t)g.blk_comp[threadIdx.x] << 24;
 		tb->ent[threadIdx.x] = make_uint4(gf->blk_dc[threadIdx.x] * (uint32_t)sizeof(JhHuffLut),
 		                                  gf->blk_ac[threadIdx.x] * (uint32_t)sizeof(JhHuffLut),
-		                                  (uint32_t)g.blk_comp[threadIdx.x] * (uint32_t)dcs_stride * 4u,
+		                                  (uint32_t)g.blk_comp[threadIdx.x] * (uint32_t)zunit,
 		                                  (int)threadIdx.x + 1 >= g.B ? 0u : threadIdx.x + 1u);
 	}
 	__syncthreads();

@@ -394,7 +394,7 @@ int jh_launch_ecs_unstuff(const JhDecodeWork &w, hipStream_t s, const JhTimerHoo
 // belongs to the thread in whose sub-sequence it STARTS: that thread decodes on past its boundary
 // until the block is complete, the next thread discards what it decodes before its first block start.
 
-#define WR_THREADS 256                 // 144 B of LDS per thread + the tables once per workgroup: 3 workgroups = 12 waves
+#define WR_THREADS 256                 // 128 B of LDS per thread + the tables once per workgroup: 3 workgroups = 12 waves
                                        // per CU.  448 threads (2 x 7 waves fill the CU's LDS) decode 3 % faster when the
                                        // decoder has the GPU to itself, but a step that encodes at the same time loses 5 %:
                                        // the encoder's workgroups then find no LDS beside them (bench `value` 80.3 against
@@ -453,23 +453,38 @@ __device__ __forceinline__ int remap_block(const JhRemap &rm, int n)
 // fblk: its index in the frame, or -1 = discard (not this lane's block).  bufs = the workgroup's block
 // buffers as 16-byte chunks, buffer of thread i = chunks [8 i, 8 i + 8), logical chunk j of thread i at
 // physical position (j + i) & 7.  The flushed buffers are zeroed for the next block.
-__device__ __forceinline__ void flush_blocks(bool fin, int fblk, int4 *bufs, int4 *frame_coefs)
+// pack: block numbers fit beside a lane number in one word (one exchange between the lanes instead of two)
+__device__ __forceinline__ void flush_blocks(bool fin, int fblk, int4 *bufs, int4 *frame_coefs, bool pack)
 {
 	const unsigned long long m = __ballot(fin);
 	if (m == 0) {
 		return;
 	}
 	const int lane = threadIdx.x & 63;
+	const int wave0 = (int)threadIdx.x - lane;
 	const int below = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
 	const int n = __popcll(m);
-	// a permutation of the lanes: the r-th finished lane hands its (block, thread) to lane r
+	// a permutation of the lanes: the r-th finished lane hands its (block, lane) to lane r
 	const int dst = fin ? below : n + (lane - below);
-	const int pblk = __builtin_amdgcn_ds_permute(dst << 2, fblk);
-	const int pthr = __builtin_amdgcn_ds_permute(dst << 2, (int)threadIdx.x);
+	int pblk, plane;
+	if (pack) {
+		pblk = __builtin_amdgcn_ds_permute(dst << 2, ((fblk + 1) << 6) | lane);
+		plane = 0;
+	} else {
+		pblk = __builtin_amdgcn_ds_permute(dst << 2, fblk);
+		plane = __builtin_amdgcn_ds_permute(dst << 2, lane);
+	}
 	for (int base = 0; base < n; base += 8) {
 		const int g = base + (lane >> 3);
-		const int sblk = __builtin_amdgcn_ds_bpermute(g << 2, pblk);
-		const int sthr = __builtin_amdgcn_ds_bpermute(g << 2, pthr);
+		int sblk, sthr;
+		if (pack) {
+			const int v = __builtin_amdgcn_ds_bpermute(g << 2, pblk);
+			sblk = (v >> 6) - 1;
+			sthr = wave0 + (v & 63);
+		} else {
+			sblk = __builtin_amdgcn_ds_bpermute(g << 2, pblk);
+			sthr = wave0 + __builtin_amdgcn_ds_bpermute(g << 2, plane);
+		}
 		if (g < n) {
 			// lane j of the group stores logical chunk j: the eight lanes write one whole 128-byte line
 			// in ascending order (rotated orders reach L2 as partial sectors, which it fills from HBM first)
@@ -485,7 +500,13 @@ __device__ __forceinline__ void flush_blocks(bool fin, int fblk, int4 *bufs, int
 }
 
 // REMAP: the scan codes one component of several (JhRemap.mode 1); a kernel of its own, so that the usual
-// case carries neither the test nor the registers
+// case carries neither the test nor the registers.
+//
+// The loop is written for its instruction count (the kernel issues: 100 vector and 76 scalar instructions per
+// symbol before this form): what happens once per sub-sequence or per restart segment -- opening the stream,
+// the careful symbol near a segment's end, undecodable data -- sits behind tests the whole wave takes together,
+// the symbol itself is straight-line code, and the DC predictors are registers (a returning LDS atomic per
+// symbol made every iteration wait for the LDS once more).
 template <bool REMAP>
 __global__ __launch_bounds__(WR_THREADS) void k_huff_write(const HuffArgs a)
 {
@@ -513,21 +534,23 @@ __global__ __launch_bounds__(WR_THREADS) void k_huff_write(const HuffArgs a)
 	for (int j = 0; j < 8; ++j) {
 		bufs[tid * 8 + j] = make_int4(0, 0, 0, 0);
 	}
-	load_tables(w, fr, luts, &tb, a.g, WR_THREADS);  // ends with a barrier
+	load_tables(w, fr, luts, &tb, a.g, WR_THREADS * 4);  // ends with a barrier
 
 	const uint32_t t = t0 + tid;
 	const uint32_t *seg_start = w.seg_start + fr.seg_off;
 	const uint32_t nseg = min(fs.nseg, fr.seg_cap - 1);
 	const int B = a.g.B, nblk = a.g.nblk;
 	const JhRemap rm = w.rm;
+	const bool pack = (REMAP ? rm.nblk_full : nblk) < (1 << 25);
 	int4 *frame_coefs = reinterpret_cast<int4 *>(w.coefs + (size_t)f * (REMAP ? rm.nblk_full : nblk) * 64);
 	int16_t *mybuf = reinterpret_cast<int16_t *>(bufs + tid * 8);
-	int *dcs = &dcs_all[0][tid];
+	const int rot = (tid & 7) << 3;                  // coefficient k of the block in progress sits at mybuf[(k + rot) & 63]
 
-	// ---- entry of this thread and of the next one -------------------------------------------------
+	// ---- entry of this thread ------------------------------------------------------------------------
 	bool act = t < nsub;
 	uint32_t pos = 0, seg = 0, seg_end = 0;
 	int c = 0, z = 0, blk = 0;
+	int *dcs = &dcs_all[0][tid];                     // DC predictors by component (decoder.c:351-355)
 	if (act) {
 		const WrEntry e = load_entry(w, fr, t);
 		pos = e.pos;
@@ -551,7 +574,7 @@ __global__ __launch_bounds__(WR_THREADS) void k_huff_write(const HuffArgs a)
 	// fast-path registers (see decode_span)
 	int cn = 0;
 	uint4 ent_n = make_uint4(0, 0, 0, 0);
-	uint32_t wi = 0, w0 = 0, w1 = 0, w2 = 0, win = 0, tac = 0, tab = 0, dca = 0;
+	uint32_t wi = 0, w0 = 0, w1 = 0, w2 = 0, win = 0, tac = 0, tab = 0, comp = 0;
 	int lastold = 0;                                 // DC predictor that went into the block in progress
 	RegStream::Cursor cur;
 	cur.b = cur.c = cur.d = 0;
@@ -567,67 +590,76 @@ __global__ __launch_bounds__(WR_THREADS) void k_huff_write(const HuffArgs a)
 		}
 		bool fin = false;
 		int fblk = -1;
-		if (go) {
-			const uint32_t fast_stop = seg_end > 31u ? seg_end - 31u : 0u;
-			bool slow = pos >= fast_stop;
-			bool isdc = z == 0;
-			int k = 0, cat = 0, val = 0;
-			bool done = false;
-			if (!slow) {
-				if (!primed) {
-					const uint4 ent = tb.ent[c];
-					cn = (int)ent.w;
-					ent_n = tb.ent[cn];
-					tac = ent.y;
-					dca = ent.z;
-					wi = pos >> 5;
-					S.open(cur, wi, w0, w1, w2);
-					win = bit_window(w0, w1, pos);
-					tab = isdc ? ent.x : tac;
-					e = *reinterpret_cast<const uint16_t *>(luts + tab + ((win >> (32 - JH_LUT_BITS)) << 1));
-					primed = true;
-				}
-				if (e & 0x8000u) {
-					e = long_code(luts + tab, e, win, isdc);
-					slow = e == 0;                 // no code matches: the careful path ends the segment
-				}
-			}
-			if (!slow) {
-				const int total = (int)(e >> 10), run = (int)((e >> 4) & 63u);
-				cat = (int)(e & 15u);
-				const uint32_t npos = pos + (uint32_t)total;
-				k = z + run;                                        // zero run (coeffs.c:246)
-				done = k >= 63;
-				// the next symbol: its table, its window, its look-up
-				const uint32_t tabn = done ? ent_n.x : tac;
-				const uint32_t nwi = npos >> 5;
-				const bool cross = nwi != wi;
-				w0 = cross ? w1 : w0;
-				w1 = cross ? w2 : w1;
-				wi = nwi;
-				const uint32_t nwin = bit_window(w0, w1, npos);
-				const unsigned en = *reinterpret_cast<const uint16_t *>(luts + tabn + ((nwin >> (32 - JH_LUT_BITS)) << 1));
-				w2 = S.next(cur, cross, w2);
-				// the current symbol's value
-				const unsigned extra = __builtin_amdgcn_ubfe(win, 32u - (unsigned)total, (unsigned)cat);
-				val = extend_sign(extra, cat);
-				int *acc = reinterpret_cast<int *>(reinterpret_cast<char *>(dcs) + dca);
-				const int old = atomicAdd(acc, isdc ? val : 0);     // DC un-prediction (decoder.c:351-355)
-				val += isdc ? old : 0;
-				lastold = isdc ? old : lastold;
-				c = done ? cn : c;
-				tac = done ? ent_n.y : tac;
-				dca = done ? ent_n.z : dca;
-				cn = done ? (int)ent_n.w : cn;
+		// symbols that start at least 31 bits before the end of the restart segment cannot run past it
+		bool fast = go && pos < (seg_end > 31u ? seg_end - 31u : 0u);
+		if (__any(fast && !primed)) {
+			if (fast && !primed) {
+				const uint4 ent = tb.ent[c];
+				cn = (int)ent.w;
 				ent_n = tb.ent[cn];
-				pos = npos;
-				win = nwin;
-				tab = tabn;
-				e = en;
-			} else {
+				tac = ent.y;
+				comp = ent.z;
+				wi = pos >> 5;
+				S.open(cur, wi, w0, w1, w2);
+				win = bit_window(w0, w1, pos);
+				tab = z == 0 ? ent.x : tac;
+				e = *reinterpret_cast<const uint16_t *>(luts + tab + ((win >> (32 - JH_LUT_BITS)) << 1));
+				primed = true;
+			}
+		}
+		if (fast && (e & 0x8000u)) {
+			e = long_code(luts + tab, e, win, z == 0);
+			fast = e != 0;                     // no code matches: the careful path ends the segment
+		}
+		if (fast) {
+			const bool isdc = z == 0;
+			const int total = (int)(e >> 10), run = (int)((e >> 4) & 63u), cat = (int)(e & 15u);
+			const uint32_t npos = pos + (uint32_t)total;
+			const int k = z + run;                                  // zero run (coeffs.c:246)
+			const bool done = k >= 63;
+			// the next symbol: its table, its window, its look-up
+			const uint32_t tabn = done ? ent_n.x : tac;
+			const uint32_t nwi = npos >> 5;
+			const bool cross = nwi != wi;
+			w0 = cross ? w1 : w0;
+			w1 = cross ? w2 : w1;
+			wi = nwi;
+			const uint32_t nwin = bit_window(w0, w1, npos);
+			const unsigned en = *reinterpret_cast<const uint16_t *>(luts + tabn + ((nwin >> (32 - JH_LUT_BITS)) << 1));
+			w2 = S.next(cur, cross, w2);
+			// the current symbol's value; DC un-prediction (decoder.c:351-355)
+			const unsigned extra = __builtin_amdgcn_ubfe(win, 32u - (unsigned)total, (unsigned)cat);
+			int val = extend_sign(extra, cat);
+			const int old = atomicAdd(reinterpret_cast<int *>(reinterpret_cast<char *>(dcs) + comp), isdc ? val : 0);
+			val += isdc ? old : 0;
+			lastold = isdc ? old : lastold;
+			// coefficient k of the block in progress; EOB and ZRL carry a zero, a run past the end (k > 63) stores one
+			mybuf[(min(k, 63) + rot) & 63] = (int16_t)(k < 64 ? val : 0);
+			z = done ? 0 : k + 1;
+			fin = done;
+			fblk = (done && own && blk >= 0 && blk < nblk) ? blk : -1;
+			if (REMAP && fblk >= 0) {
+				fblk = remap_block(rm, fblk);
+			}
+			own = own || done;
+			blk += done ? 1 : 0;
+			c = done ? cn : c;
+			tac = done ? ent_n.y : tac;
+			comp = done ? ent_n.z : comp;
+			cn = done ? (int)ent_n.w : cn;
+			ent_n = tb.ent[cn];
+			pos = npos;
+			win = nwin;
+			tab = tabn;
+			e = en;
+		}
+		if (__any(go && !fast)) {
+			if (go && !fast) {
 				// ---- careful: one symbol with every test of read_block(), stream read from global memory
 				primed = false;
+				const bool isdc = z == 0;
 				const uint32_t info = tb.info[c];
+				const uint32_t kc = info >> 24;
 				const unsigned char *tb1 = luts + (((info >> (isdc ? 0 : 12)) & 0xfffu) << 4);
 				const uint32_t wj = pos >> 5;
 				const uint32_t wn = bit_window(G.word(wj), G.word(wj + 1), pos);
@@ -635,8 +667,7 @@ __global__ __launch_bounds__(WR_THREADS) void k_huff_write(const HuffArgs a)
 				if (e1 & 0x8000u) {
 					e1 = long_code(tb1, e1, wn, isdc);
 				}
-				const int total = (int)(e1 >> 10), run = (int)((e1 >> 4) & 63u);
-				cat = (int)(e1 & 15u);
+				const int total = (int)(e1 >> 10), run = (int)((e1 >> 4) & 63u), cat = (int)(e1 & 15u);
 				const uint32_t npos = pos + (uint32_t)total;
 				if (e1 == 0 || npos > seg_end) {
 					// End of this restart segment (decoder.c:376-381): the MCU in progress is not counted, the next
@@ -657,7 +688,7 @@ __global__ __launch_bounds__(WR_THREADS) void k_huff_write(const HuffArgs a)
 						}
 					}
 					if (partial) {
-						mybuf[(tid & 7) << 3] -= (int16_t)lastold;     // coefficient 0 sits in chunk (0 + tid) & 7
+						mybuf[rot] -= (int16_t)lastold;             // coefficient 0
 						fin = true;
 						fblk = (own && blk >= 0 && blk < nblk) ? blk : -1;
 						if (REMAP && fblk >= 0) {
@@ -679,37 +710,32 @@ __global__ __launch_bounds__(WR_THREADS) void k_huff_write(const HuffArgs a)
 						pos = seg_end;
 						seg_end = min(seg_start[seg + 1] * 8u, total_bits);
 					}
-					k = -1;                        // no coefficient this round
 				} else {
 					const unsigned extra = __builtin_amdgcn_ubfe(wn, 32u - (unsigned)total, (unsigned)cat);
-					val = extend_sign(extra, cat);
+					int val = extend_sign(extra, cat);
 					if (isdc) {
-						lastold = atomicAdd(dcs + (info >> 24) * WR_THREADS, val);
+						lastold = atomicAdd(dcs + kc * WR_THREADS, val);
 						val += lastold;
 					}
-					k = z + run;
-					done = k >= 63;
+					const int k = z + run;
+					const bool done = k >= 63;
+					mybuf[(min(k, 63) + rot) & 63] = (int16_t)(k < 64 ? val : 0);
 					pos = npos;
-					c = done ? ((c + 1 == B) ? 0 : c + 1) : c;
-				}
-			}
-			if (k >= 0) {
-				// coefficient k of the block in progress; EOB / ZRL / runs past the end store a harmless zero
-				const int kk = min(k, 63);
-				mybuf[((((kk >> 3) + tid) & 7) << 3) + (kk & 7)] = (int16_t)((k < 64 && (isdc || cat != 0)) ? val : 0);
-				z = done ? 0 : k + 1;
-				if (done) {
-					fin = true;
-					fblk = (own && blk >= 0 && blk < nblk) ? blk : -1;
-					if (REMAP && fblk >= 0) {
-						fblk = remap_block(rm, fblk);
+					z = done ? 0 : k + 1;
+					if (done) {
+						c = (c + 1 == B) ? 0 : c + 1;
+						fin = true;
+						fblk = (own && blk >= 0 && blk < nblk) ? blk : -1;
+						if (REMAP && fblk >= 0) {
+							fblk = remap_block(rm, fblk);
+						}
+						own = true;
+						blk++;
 					}
-					own = true;
-					blk++;
 				}
 			}
 		}
-		flush_blocks(fin, fblk, bufs, frame_coefs);
+		flush_blocks(fin, fblk, bufs, frame_coefs, pack);
 	}
 }
 

@@ -284,7 +284,7 @@ __global__ __launch_bounds__(256) void k_huff_chains(const HuffArgs a)
 	if (blockIdx.x * 256u >= nsub) {
 		return;
 	}
-	load_tables(w, fr, luts, &tb, a.g, 256);              // ends with a barrier, the only one
+	load_tables(w, fr, luts, &tb, a.g, 256 * 4);              // ends with a barrier, the only one
 	const int tid = threadIdx.x;
 	const uint32_t t = blockIdx.x * 256u + tid;
 	if (t >= nsub) {
@@ -380,7 +380,7 @@ __global__ __launch_bounds__(256) void k_huff_survivors(const HuffArgs a)
 	}
 	const uint32_t total_bits = fs.cs_len * 8u;
 	const uint32_t nsub = (total_bits + JH_SUBSEQ_BITS - 1) / JH_SUBSEQ_BITS;
-	load_tables(w, fr, luts, &tb, a.g, 256);
+	load_tables(w, fr, luts, &tb, a.g, 256 * 4);
 	const int tid = threadIdx.x;
 	if (blockIdx.x * 256u + tid >= nsurv) {
 		return;
@@ -670,7 +670,7 @@ __global__ __launch_bounds__(64) void k_huff_walk(const HuffArgs a)
 	if (!mismatch && !gap) {
 		return;
 	}
-	load_tables(w, fr, luts, &tb, a.g, 64);
+	load_tables(w, fr, luts, &tb, a.g, 64 * 4);
 	for (int jl = lo + lane; jl <= hi; jl += 64) {
 		prl[jl] = prec[jl];
 	}
@@ -891,7 +891,7 @@ __global__ __launch_bounds__(64) void k_huff_finish(const HuffArgs a)
 	}
 	const uint32_t nwg = jh_num_chain_wgs(nsub);
 	if (fs.status & JH_ST_SERIAL) {
-		load_tables(w, fr, luts, &tb, a.g, 64);
+		load_tables(w, fr, luts, &tb, a.g, 64 * 4);
 		if (threadIdx.x == 0) {
 			serial_walk(a, fr, fs, nsub, nwg, luts, tb, &dcs[0][0]);
 		}
@@ -914,7 +914,7 @@ __global__ __launch_bounds__(64) void k_huff_finish(const HuffArgs a)
 			fs.status |= JH_ST_SERIAL;
 			fs.serial_cause |= 2u;
 		}
-		load_tables(w, fr, luts, &tb, a.g, 64);
+		load_tables(w, fr, luts, &tb, a.g, 64 * 4);
 		if (threadIdx.x == 0) {
 			serial_walk(a, fr, fs, nsub, nwg, luts, tb, &dcs[0][0]);
 		}

@@ -33,6 +33,7 @@ def main():
     te = bench.timed(torch, lambda: enc.run(samples), 10, 2, None) / 10
     dec.sync()
     stats = [dec.stats(f) for f in range(F)]
+    print("chain steps, frame 0:", dec.chain_steps(0))
     print("stats (serial, repaired, blocks, segments):", stats[:4], "serial frames", sum(s[0] for s in stats),
           "repaired wgs", sum(s[1] for s in stats))
     print(json.dumps({"config": name, "frames": F, "jpg_bytes": len(jpgs[0]),
