@@ -2053,6 +2053,54 @@ static void spec_from_htable(const jpeg_hip_htable *t, JhHuffSpec *s)
 	memcpy(s->V, t->V, 256);
 }
 
+// The stage-level calls below work on host memory, one image per call.  Their device objects and buffers are kept
+// per device between calls and only grow (hipMalloc / hipFree wait for every stream of the device); a call holds
+// the device's set for its duration, so calls on one device take turns.  Held until the process ends.
+struct StageObjects {
+	std::mutex m;
+	jpeg_hip_decoder *dec = nullptr;
+	jpeg_hip_encoder *enc = nullptr;
+	void *buf[3] = {nullptr, nullptr, nullptr};
+	size_t cap[3] = {0, 0, 0};
+	void *buffer(int slot, size_t bytes)
+	{
+		if (cap[slot] < bytes || !buf[slot]) {
+			if (buf[slot]) {
+				hipFree(buf[slot]);
+				buf[slot] = nullptr;
+				cap[slot] = 0;
+			}
+			const size_t want = bytes + bytes / 4 + 256;
+			if (hipMalloc(&buf[slot], want) != hipSuccess) {
+				buf[slot] = nullptr;
+				return nullptr;
+			}
+			cap[slot] = want;
+		}
+		return buf[slot];
+	}
+	int decoder(int device, jpeg_hip_decoder **out)
+	{
+		const int err = dec ? RET_SUCCESS : jpeg_hip_decoder_create(&dec, device);
+		*out = dec;
+		return err;
+	}
+	int encoder(int device, jpeg_hip_encoder **out)
+	{
+		const int err = enc ? RET_SUCCESS : jpeg_hip_encoder_create(&enc, device);
+		*out = enc;
+		return err;
+	}
+};
+
+static StageObjects &stage_objects(int device)
+{
+	static std::mutex all_m;
+	static std::map<int, StageObjects> all;
+	std::lock_guard<std::mutex> lk(all_m);
+	return all[device];
+}
+
 extern "C" int jpeg_hip_read_scan(int device, const jpeg_hip_frame_desc *frame, const jpeg_hip_scan_desc *scan,
                                   const jpeg_hip_htable dc[4], const jpeg_hip_htable ac[4],
                                   const uint8_t *ecs, size_t n, int32_t *const coef[JPEG_HIP_MAX_COMP], size_t *consumed)
@@ -2117,8 +2165,10 @@ extern "C" int jpeg_hip_read_scan(int device, const jpeg_hip_frame_desc *frame, 
 		}
 	}
 
+	StageObjects &so = stage_objects(device);
+	std::lock_guard<std::mutex> lease(so.m);
 	jpeg_hip_decoder *dec = nullptr;
-	err = jpeg_hip_decoder_create(&dec, device);
+	err = so.decoder(device, &dec);
 	if (err) {
 		return err;
 	}
@@ -2152,7 +2202,6 @@ extern "C" int jpeg_hip_read_scan(int device, const jpeg_hip_frame_desc *frame, 
 			}
 		}
 	}
-	jpeg_hip_decoder_destroy(dec);
 	return err ? err : status;
 }
 
@@ -2191,12 +2240,12 @@ extern "C" int jpeg_hip_decode_pixels(int device, const jpeg_hip_frame_desc *fra
 		}
 	}
 	const size_t body = (size_t)g.X * g.Y * g.out_comps * g.sample_bytes;
-	int16_t *d_coefs = nullptr;
-	JhQuant *d_quant = nullptr;
-	void *d_out = nullptr;
-	hipError_t e = hipMalloc((void **)&d_coefs, ncoef * sizeof(int16_t));
-	e = e == hipSuccess ? hipMalloc((void **)&d_quant, sizeof q) : e;
-	e = e == hipSuccess ? hipMalloc(&d_out, body) : e;
+	StageObjects &so = stage_objects(device);
+	std::lock_guard<std::mutex> lease(so.m);
+	int16_t *d_coefs = (int16_t *)so.buffer(0, ncoef * sizeof(int16_t));
+	JhQuant *d_quant = (JhQuant *)so.buffer(1, sizeof q);
+	void *d_out = so.buffer(2, body ? body : 1);
+	hipError_t e = d_coefs && d_quant && d_out ? hipSuccess : hipErrorOutOfMemory;
 	e = e == hipSuccess ? hipMemcpy(d_coefs, fc.data(), ncoef * sizeof(int16_t), hipMemcpyHostToDevice) : e;
 	e = e == hipSuccess ? hipMemcpy(d_quant, &q, sizeof q, hipMemcpyHostToDevice) : e;
 	int r = RET_SUCCESS;
@@ -2207,9 +2256,6 @@ extern "C" int jpeg_hip_decode_pixels(int device, const jpeg_hip_frame_desc *fra
 	} else if (hipMemcpy(samples, d_out, body, hipMemcpyDeviceToHost) != hipSuccess) {
 		r = RET_FAILURE_LOGIC_ERROR;
 	}
-	hipFree(d_coefs);
-	hipFree(d_quant);
-	hipFree(d_out);
 	return r;
 }
 
@@ -2257,17 +2303,20 @@ extern "C" int jpeg_hip_encode_pixels(int device, const jpeg_hip_frame_desc *fra
 			}
 		}
 	}
+	StageObjects &so = stage_objects(device);
+	std::lock_guard<std::mutex> lease(so.m);
 	jpeg_hip_encoder *enc = nullptr;
-	err = jpeg_hip_encoder_create(&enc, device);
+	err = so.encoder(device, &enc);
 	if (err) {
 		return err;
 	}
+	enc->restart_interval = 0;
 	err = encoder_configure(enc, 1, frame->X, frame->Y, frame->Nf, frame->P, &prm, Q, nullptr);
-	void *d_in = nullptr;
 	if (!err) {
 		const JhGeom &g = enc->g;
 		const size_t body = (size_t)g.X * g.Y * g.Nf * g.sample_bytes;
-		if (hipMalloc(&d_in, body) != hipSuccess || hipMemcpy(d_in, samples, body, hipMemcpyHostToDevice) != hipSuccess) {
+		void *d_in = so.buffer(0, body ? body : 1);
+		if (!d_in || hipMemcpy(d_in, samples, body, hipMemcpyHostToDevice) != hipSuccess) {
 			err = RET_FAILURE_MEMORY_ALLOCATION;
 		} else if (jh_launch_encode_pixels(g, 1, d_in, body, enc->d_quant, enc->d_coefs, nullptr, nullptr, nullptr, nullptr) ||
 		           hipStreamSynchronize(nullptr) != hipSuccess) {
@@ -2280,14 +2329,12 @@ extern "C" int jpeg_hip_encode_pixels(int device, const jpeg_hip_frame_desc *fra
 			}
 		}
 	}
-	hipFree(d_in);
-	jpeg_hip_encoder_destroy(enc);
 	return err;
 }
 
 // what jpeg_hip_write_scan() and jpeg_hip_adapt_tables() share: an encoder object for one frame of the caller's
 // description with the caller's coefficients uploaded (scan order, zig-zag, int16)
-static int scan_encoder(int device, const jpeg_hip_frame_desc *frame, const jpeg_hip_scan_desc *scan,
+static int scan_encoder(StageObjects &so, int device, const jpeg_hip_frame_desc *frame, const jpeg_hip_scan_desc *scan,
                         const jpeg_hip_htable dc[4], const jpeg_hip_htable ac[4], int optimize,
                         const int32_t *const coef[JPEG_HIP_MAX_COMP], jpeg_hip_encoder **out_enc)
 {
@@ -2321,7 +2368,7 @@ static int scan_encoder(int device, const jpeg_hip_frame_desc *frame, const jpeg
 		}
 	}
 	jpeg_hip_encoder *enc = nullptr;
-	err = jpeg_hip_encoder_create(&enc, device);
+	err = so.encoder(device, &enc);
 	if (err) {
 		return err;
 	}
@@ -2343,7 +2390,6 @@ static int scan_encoder(int device, const jpeg_hip_frame_desc *frame, const jpeg
 		}
 	}
 	if (err) {
-		jpeg_hip_encoder_destroy(enc);
 		return err;
 	}
 	*out_enc = enc;
@@ -2379,7 +2425,9 @@ extern "C" int jpeg_hip_write_scan(int device, const jpeg_hip_frame_desc *frame,
 	}
 	*n = 0;
 	jpeg_hip_encoder *enc = nullptr;
-	err = scan_encoder(device, frame, scan, dc, ac, optimize, coef, &enc);
+	StageObjects &so = stage_objects(device);
+	std::lock_guard<std::mutex> lease(so.m);
+	err = scan_encoder(so, device, frame, scan, dc, ac, optimize, coef, &enc);
 	if (err) {
 		return err;
 	}
@@ -2408,7 +2456,6 @@ extern "C" int jpeg_hip_write_scan(int device, const jpeg_hip_frame_desc *frame,
 			err = fetch_adapted_tables(enc, frame->Nf, dc, ac);
 		}
 	}
-	jpeg_hip_encoder_destroy(enc);
 	return err;
 }
 
@@ -2424,7 +2471,9 @@ extern "C" int jpeg_hip_adapt_tables(int device, const jpeg_hip_frame_desc *fram
 		return RET_FAILURE_LOGIC_ERROR;
 	}
 	jpeg_hip_encoder *enc = nullptr;
-	err = scan_encoder(device, frame, scan, dc, ac, 1, coef, &enc);
+	StageObjects &so = stage_objects(device);
+	std::lock_guard<std::mutex> lease(so.m);
+	err = scan_encoder(so, device, frame, scan, dc, ac, 1, coef, &enc);
 	if (err) {
 		return err;
 	}
@@ -2435,7 +2484,6 @@ extern "C" int jpeg_hip_adapt_tables(int device, const jpeg_hip_frame_desc *fram
 	if (!err) {
 		err = fetch_adapted_tables(enc, frame->Nf, dc, ac);
 	}
-	jpeg_hip_encoder_destroy(enc);
 	return err;
 }
 
