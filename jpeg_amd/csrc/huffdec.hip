@@ -569,8 +569,10 @@ __global__ __launch_bounds__(WR_THREADS) void k_huff_write(const HuffArgs a)
 		}
 	}
 	const uint32_t stop = (t + 1) * JH_SUBSEQ_BITS;
-	bool own = z == 0;                               // a thread that enters mid-block does not own that block
-	bool primed = false;
+	// the thread's flags live in ONE vector register: kept as wave masks they cost a dozen scalar instructions per
+	// symbol to merge at the ends of the divergent regions, and the scalar unit is shared by the CU's four SIMDs
+	enum { F_ACT = 1, F_OWN = 2, F_PRIMED = 4 };
+	unsigned fl = (act ? F_ACT : 0u) | (z == 0 ? F_OWN : 0u);   // a thread that enters mid-block does not own that block
 	// fast-path registers (see decode_span)
 	int cn = 0;
 	uint4 ent_n = make_uint4(0, 0, 0, 0);
@@ -584,16 +586,16 @@ __global__ __launch_bounds__(WR_THREADS) void k_huff_write(const HuffArgs a)
 	unsigned e = 0;
 
 	for (;;) {
-		const bool go = act && (pos < stop || z != 0);
-		if (!__any(go)) {
+		const bool go = (fl & F_ACT) && (pos < stop || z != 0);
+		if (__builtin_amdgcn_ballot_w64(go) == 0) {
 			break;
 		}
 		bool fin = false;
 		int fblk = -1;
 		// symbols that start at least 31 bits before the end of the restart segment cannot run past it
 		bool fast = go && pos < (seg_end > 31u ? seg_end - 31u : 0u);
-		if (__any(fast && !primed)) {
-			if (fast && !primed) {
+		if (__builtin_amdgcn_ballot_w64(fast && !(fl & F_PRIMED)) != 0) {
+			if (fast && !(fl & F_PRIMED)) {
 				const uint4 ent = tb.ent[c];
 				cn = (int)ent.w;
 				ent_n = tb.ent[cn];
@@ -604,7 +606,7 @@ __global__ __launch_bounds__(WR_THREADS) void k_huff_write(const HuffArgs a)
 				win = bit_window(w0, w1, pos);
 				tab = z == 0 ? ent.x : tac;
 				e = *reinterpret_cast<const uint16_t *>(luts + tab + ((win >> (32 - JH_LUT_BITS)) << 1));
-				primed = true;
+				fl |= F_PRIMED;
 			}
 		}
 		if (fast && (e & 0x8000u)) {
@@ -637,11 +639,11 @@ __global__ __launch_bounds__(WR_THREADS) void k_huff_write(const HuffArgs a)
 			mybuf[(min(k, 63) + rot) & 63] = (int16_t)(k < 64 ? val : 0);
 			z = done ? 0 : k + 1;
 			fin = done;
-			fblk = (done && own && blk >= 0 && blk < nblk) ? blk : -1;
+			fblk = (done && (fl & F_OWN) && (unsigned)blk < (unsigned)nblk) ? blk : -1;
 			if (REMAP && fblk >= 0) {
 				fblk = remap_block(rm, fblk);
 			}
-			own = own || done;
+			fl |= done ? (unsigned)F_OWN : 0u;
 			blk += done ? 1 : 0;
 			c = done ? cn : c;
 			tac = done ? ent_n.y : tac;
@@ -653,10 +655,10 @@ __global__ __launch_bounds__(WR_THREADS) void k_huff_write(const HuffArgs a)
 			tab = tabn;
 			e = en;
 		}
-		if (__any(go && !fast)) {
+		if (__builtin_amdgcn_ballot_w64(go && !fast) != 0) {
 			if (go && !fast) {
 				// ---- careful: one symbol with every test of read_block(), stream read from global memory
-				primed = false;
+				fl &= ~(unsigned)F_PRIMED;
 				const bool isdc = z == 0;
 				const uint32_t info = tb.info[c];
 				const uint32_t kc = info >> 24;
@@ -690,7 +692,7 @@ __global__ __launch_bounds__(WR_THREADS) void k_huff_write(const HuffArgs a)
 					if (partial) {
 						mybuf[rot] -= (int16_t)lastold;             // coefficient 0
 						fin = true;
-						fblk = (own && blk >= 0 && blk < nblk) ? blk : -1;
+						fblk = ((fl & F_OWN) && blk >= 0 && blk < nblk) ? blk : -1;
 						if (REMAP && fblk >= 0) {
 							fblk = remap_block(rm, fblk);
 						}
@@ -698,14 +700,14 @@ __global__ __launch_bounds__(WR_THREADS) void k_huff_write(const HuffArgs a)
 					blk -= c;
 					c = 0;
 					z = 0;
-					own = true;
+					fl |= F_OWN;
 #pragma unroll
 					for (int q = 0; q < JH_MAX_COMP; ++q) {
 						DCS_AT(dcs, q, WR_THREADS) = 0;
 					}
 					seg++;
 					if (seg >= nseg) {
-						act = false;
+						fl &= ~(unsigned)F_ACT;
 					} else {
 						pos = seg_end;
 						seg_end = min(seg_start[seg + 1] * 8u, total_bits);
@@ -725,11 +727,11 @@ __global__ __launch_bounds__(WR_THREADS) void k_huff_write(const HuffArgs a)
 					if (done) {
 						c = (c + 1 == B) ? 0 : c + 1;
 						fin = true;
-						fblk = (own && blk >= 0 && blk < nblk) ? blk : -1;
+						fblk = ((fl & F_OWN) && blk >= 0 && blk < nblk) ? blk : -1;
 						if (REMAP && fblk >= 0) {
 							fblk = remap_block(rm, fblk);
 						}
-						own = true;
+						fl |= F_OWN;
 						blk++;
 					}
 				}
