@@ -442,6 +442,20 @@ def main():
         "encode_mpix_s": round(world * F * pix * args.steps / t_e / 1e6, 1),
     }
 
+    if rank == 0 and world == 1 and not args.no_workloads:
+        # The decoder's synchronisation ends in a few narrow kernels whose time does not shrink with the batch (the
+        # slowest chains decide it): a second decoder on twice the frames shows what they cost at this batch size.
+        dec2 = binding.Decoder(dev)
+        dec2.prepare(jpgs + jpgs)
+        out2 = dec2.alloc_output()
+        dec2.run(out2)
+        assert all(s == 0 for s in dec2.sync())
+        n2 = max(3, args.steps // 2)
+        t2 = timed(torch, lambda: dec2.run(out2), n2, 1, None)
+        res["decode_mpix_s_at_%d_frames" % (2 * F)] = round(2 * F * pix * n2 / t2 / 1e6, 1)
+        dec2.close()
+        del out2
+
     if rank == 0:
         # ---- roofline of the dominant kernel, live HIP-event timing on the launch stream ----
         kd = kernel_times(dec, lambda: dec.run(out), torch)
