@@ -262,10 +262,16 @@ __device__ __forceinline__ void store_agg(JhWgAgg *dst, const Agg &t, uint32_t e
 // (One kernel did all of this before, with the survivors' steps as sparse rounds between workgroup barriers:
 // those rounds took 29 % of its time for an eighth of the work, while the LDS of the whole workgroup stayed taken.)
 
-// the chain ran off the end of the data (no code matched, no restart segment left) before the stream was over
+// The chain met bits no code matches before the stream was over: it ran off the end of the data (no restart
+// segment left), or skipped to the start of the next restart segment as read_ecs() does (decoder.c:376-381) and
+// that lies behind the whole of the next sub-sequence.  For a guess that is the end of its use -- the next chain's
+// guess takes over (restart link) -- and cheap to say: left alone, such a chain idles through its sixteen steps
+// towards that segment, links to nothing, and a workgroup range whose path starts with it has to be walked again
+// (with optimised tables, where many codes do not exist, one chain in a hundred is of this kind).
 __device__ __forceinline__ bool rec_garbage(const JhSubInfo &r, uint32_t total_bits, uint32_t next_sub, uint32_t nsub)
 {
-	return (uint32_t)(r.state & 0xffffffffu) >= total_bits && next_sub < nsub;
+	const uint32_t pos = (uint32_t)(r.state & 0xffffffffu);
+	return next_sub < nsub && (pos >= total_bits || pos >= (next_sub + 1u) * JH_SUBSEQ_BITS);
 }
 
 __global__ __launch_bounds__(256) void k_huff_chains(const HuffArgs a)
@@ -303,8 +309,8 @@ __global__ __launch_bounds__(256) void k_huff_chains(const HuffArgs a)
 	st.seg = nseg > 1 ? find_segment(seg_start, nseg, st.pos >> 3) : 0u;
 	decode_span<false>(st, (t + 1) * JH_SUBSEQ_BITS, S, total_bits, seg_start, nseg, luts, tb, a.g.B, mydcs, 256, nullptr, 0, 0);
 	store_info(&rec[0], st);
-	if (st.pos >= total_bits || t + 1 >= nsub) {
-		return;                            // garbage (k_huff_links restarts with the next chain's guess), or the last one
+	if (st.pos >= total_bits || st.pos >= (t + 2) * JH_SUBSEQ_BITS || t + 1 >= nsub) {
+		return;                            // garbage (rec_garbage: k_huff_links restarts with the next chain's guess), or the last one
 	}
 	// step 1: the next sub-sequence from where step 0 ended (sums counted anew)
 	const unsigned long long ps = pack_state(st);
@@ -403,8 +409,8 @@ __global__ __launch_bounds__(256) void k_huff_survivors(const HuffArgs a)
 		decode_span<false>(st, (jl + 1) * JH_SUBSEQ_BITS, S, total_bits, seg_start, nseg, luts, tb, a.g.B, mydcs, 256, nullptr, 0, 0);
 		store_info(&rec[d], st);
 		meta = d;
-		if (st.pos >= total_bits && jl + 1 < nsub) {
-			meta |= ((d + 1u) << 8) | META_RESTART;        // garbage: restart with the next chain's guess
+		if ((st.pos >= total_bits || st.pos >= (jl + 2u) * JH_SUBSEQ_BITS) && jl + 1 < nsub) {
+			meta |= ((d + 1u) << 8) | META_RESTART;        // garbage (rec_garbage): restart with the next chain's guess
 			break;
 		}
 		ps = pack_state(st);

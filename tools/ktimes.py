@@ -17,7 +17,7 @@ def main():
     F = int(sys.argv[2]) if len(sys.argv) > 2 else 16
     reps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
     torch.cuda.set_device(0)
-    enc, samples, jpgs, cfg = bench.make_batch(torch, binding, synth, name, F, 0)
+    enc, samples, jpgs, cfg = bench.make_batch(torch, binding, synth, name, F, 0, int(os.environ.get("KT_RI", "0")))
     dec = binding.Decoder(0)
     dec.prepare(jpgs)
     dec.set_debug(int(os.environ.get("KT_DEBUG", "0")))
@@ -33,7 +33,10 @@ def main():
     te = bench.timed(torch, lambda: enc.run(samples), 10, 2, None) / 10
     dec.sync()
     stats = [dec.stats(f) for f in range(F)]
-    print("chain steps, frame 0:", dec.chain_steps(0))
+    try:
+        print("chain steps, frame 0:", dec.chain_steps(0))
+    except AttributeError:
+        pass
     print("stats (serial, repaired, blocks, segments):", stats[:4], "serial frames", sum(s[0] for s in stats),
           "repaired wgs", sum(s[1] for s in stats))
     print(json.dumps({"config": name, "frames": F, "jpg_bytes": len(jpgs[0]),
