@@ -194,6 +194,7 @@ struct DecPass {
 	std::vector<JhHuffLut> luts;
 	size_t cs_off = 0, seg_off = 0, chunk_off = 0, sub_off = 0, wg_off = 0;
 	uint32_t max_chunks = 1, max_subs = 1, max_luts = 1;
+	int segmented = 0;                // a frame's scan came with a restart interval (DRI)
 	JhDecodeWork work{};
 
 	void release()
@@ -566,6 +567,7 @@ static int decoder_prepare(jpeg_hip_decoder *dec, int nframes, const uint8_t *co
 		ps.g = G;
 		ps.luts.clear();
 		ps.cs_off = ps.seg_off = ps.chunk_off = ps.sub_off = ps.wg_off = 0;
+		ps.segmented = 0;
 		ps.max_chunks = ps.max_subs = ps.max_luts = 1;
 		JhRemap rm;
 		memset(&rm, 0, sizeof rm);
@@ -632,6 +634,7 @@ static int decoder_prepare(jpeg_hip_decoder *dec, int nframes, const uint8_t *co
 				continue;
 			}
 			const ScanDesc &sd = scans[f][pi];
+			ps.segmented |= sd.Ri > 0;
 			fr.raw_begin = (uint32_t)(file_off[f] + sd.ecs_begin);
 			fr.raw_end = (uint32_t)(file_off[f] + sd.ecs_end);
 			const size_t ecs = sd.ecs_end - sd.ecs_begin;
@@ -854,6 +857,7 @@ static int decoder_prepare(jpeg_hip_decoder *dec, int nframes, const uint8_t *co
 		w.max_subs = ps.max_subs;
 		w.max_luts = ps.max_luts;
 		w.debug = dec->debug;
+		w.segmented = ps.segmented;
 	}
 	dec->nframes = nframes;
 	return RET_SUCCESS;

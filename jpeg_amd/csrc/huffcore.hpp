@@ -152,24 +152,205 @@ __device__ __forceinline__ unsigned long_code(const unsigned char *tab, unsigned
 	return (((unsigned)len + cat) << 10) | (run << 4) | cat;
 }
 
-// Decode every symbol that STARTS before bit `stop`, beginning at st.pos.  WRITE selects the final
-// pass (coefficients stored, st.dc = predictors, blk = index of the block in progress).
+// Decode every symbol that STARTS before bit `stop`, beginning at st.pos (sums of DC differences and blocks only:
+// the synchronisation kernels; the write pass has its own loop with the same symbol core, huffdec.hip).
 //
-// Two regions.  FAST: symbols that start at least 31 bits before the end of the restart segment cannot
-// run past it, so the loop needs no end-of-segment test; it is software-pipelined by hand -- the
-// table look-up of the NEXT symbol is issued as soon as the current symbol's length is known, the
-// value extraction and the bookkeeping of the current symbol run in its shadow -- and branch-free
-// apart from the rare long code and the coefficient store.  Three stream words are kept in registers
-// (w0:w1 hold the current bit, w2 the word after them, re-read every iteration), and the tables of the
-// next block of the MCU are fetched while the current block is being decoded.  CAREFUL: one symbol
-// with every test of the reference's read_block(), used near segment ends and for undecodable data.
-template <bool WRITE, class Stream>
-__device__ __forceinline__ void decode_span(DecState &st, const uint32_t stop, const Stream &S,
+// One loop, one symbol per trip and lane.  FAST: symbols that start at least 31 bits before the end of the restart
+// segment cannot run past it, so they need no end-of-segment test; the code is software-pipelined by hand -- the
+// table look-up of the NEXT symbol is issued as soon as the current symbol's length is known, the value
+// extraction and the bookkeeping of the current symbol run in its shadow -- and branch-free apart from the rare
+// long code.  Three stream words are kept in registers (w0:w1 hold the current bit, w2 the word after them), and
+// the tables of the next block of the MCU are fetched while the current block is being decoded.  CAREFUL: one
+// symbol with every test of the reference's read_block(), used near segment ends and for undecodable data, behind
+// a test the whole wave takes together.  (The two used to be an inner loop and its tail: a lane that met a
+// segment end early then waited for the others' inner loops and decoded the rest of its sub-sequence alone
+// afterwards -- with a restart interval per MCU row the kernels took twice as long.)
+template <class Stream>
+__device__ __forceinline__ void decode_span_segmented(DecState &st, const uint32_t stop, const Stream &S,
                                             const uint32_t total_bits, const uint32_t *seg_start,
                                             const uint32_t nseg, const unsigned char *luts,
                                             const DecTables &tb, const int B, int *dcs, const int dcs_stride,
                                             int16_t *coefs, int blk, const int nblk)
 {
+	if (st.pos >= stop || st.pos >= total_bits) {
+		return;
+	}
+#pragma unroll
+	for (int k = 0; k < JH_MAX_COMP; ++k) {
+		DCS_AT(dcs, k, dcs_stride) = st.dc[k];
+	}
+	uint32_t seg_end = min(seg_start[st.seg + 1] * 8u, total_bits);
+	uint32_t pos = st.pos;
+	int c = st.c, z = st.z, nb = st.nb;
+	bool primed = false;
+	int cn = 0;
+	uint4 ent_n = make_uint4(0, 0, 0, 0);
+	uint32_t wi = 0, w0 = 0, w1 = 0, w2 = 0, win = 0, tac = 0, tab = 0, dca = 0;
+	typename Stream::Cursor cur;
+	cur.b = cur.c = cur.d = 0;
+	cur.nq = 4;
+	cur.nxt = 0;
+	cur.ld.x = cur.ld.y = cur.ld.z = cur.ld.w = 0;
+	unsigned e = 0;
+
+	const bool segmented = nseg > 1;                       // restart segments: a lane may meet a segment end anywhere
+	for (;;) {
+		const bool go = pos < stop && pos < total_bits;
+		if (__builtin_amdgcn_ballot_w64(go) == 0) {
+			break;
+		}
+		// symbols that start before `fs` take the fast path; an undecodable code pulls `fs` back to its position
+		uint32_t fs = go ? min(stop, seg_end > 31u ? seg_end - 31u : 0u) : 0u;
+		if (__builtin_amdgcn_ballot_w64(pos < fs && !primed) != 0) {
+			if (pos < fs && !primed) {
+				const uint4 ent = tb.ent[c];
+				cn = (int)ent.w;
+				ent_n = tb.ent[cn];
+				tac = ent.y;
+				dca = ent.z;
+				wi = pos >> 5;
+				S.open(cur, wi, w0, w1, w2);
+				win = bit_window(w0, w1, pos);
+				tab = z == 0 ? ent.x : tac;
+				e = *reinterpret_cast<const uint16_t *>(luts + tab + ((win >> (32 - JH_LUT_BITS)) << 1));
+				primed = true;
+			}
+		}
+		// one fast symbol of this lane (pos < fs)
+		auto symbol = [&]() {
+			const bool isdc = z == 0;
+			bool ok = true;
+			if (e & 0x8000u) {
+				e = long_code(luts + tab, e, win, isdc);
+				ok = e != 0;
+				fs = ok ? fs : pos;            // no code matches: the careful path ends the segment
+			}
+			if (ok) {
+				const int total = (int)(e >> 10), run = (int)((e >> 4) & 63u), cat = (int)(e & 15u);
+				const uint32_t npos = pos + (uint32_t)total;
+				const int k = z + run;                              // zero run (coeffs.c:246)
+				const bool done = k >= 63;
+				// the next symbol: its table, its window, its look-up
+				const uint32_t tabn = done ? ent_n.x : tac;
+				const uint32_t nwi = npos >> 5;
+				const bool cross = nwi != wi;                       // a symbol has at most 31 bits
+				w0 = cross ? w1 : w0;
+				w1 = cross ? w2 : w1;
+				wi = nwi;
+				const uint32_t nwin = bit_window(w0, w1, npos);
+				const unsigned en = *reinterpret_cast<const uint16_t *>(luts + tabn + ((nwin >> (32 - JH_LUT_BITS)) << 1));
+				w2 = S.next(cur, cross, w2);
+				// the current symbol's value: only the DC differences are summed here
+				const unsigned extra = __builtin_amdgcn_ubfe(win, 32u - (unsigned)total, (unsigned)cat);
+				const int val = extend_sign(extra, cat);
+				atomicAdd(reinterpret_cast<int *>(reinterpret_cast<char *>(dcs) + dca), isdc ? val : 0);
+				// next zig-zag index / next block
+				z = done ? 0 : k + 1;
+				nb += done ? 1 : 0;
+				c = done ? cn : c;
+				tac = done ? ent_n.y : tac;
+				dca = done ? ent_n.z : dca;
+				cn = done ? (int)ent_n.w : cn;
+				ent_n = tb.ent[cn];
+				pos = npos;
+				win = nwin;
+				tab = tabn;
+				e = en;
+			}
+		};
+		if (!segmented) {
+			// one segment: the careful path is for the last bits of the stream only; every lane runs to its `fs`
+			while (pos < fs) {
+				symbol();
+			}
+		} else {
+			// Restart segments: the loop ends as soon as a lane waits for the careful path -- a lane that met a
+			// segment end would otherwise sit out the others' sub-sequences and decode the rest of its own alone
+			// afterwards.
+			for (;;) {
+				const bool fast = pos < fs;
+				if (__builtin_amdgcn_ballot_w64(fast) == 0 ||
+				    __builtin_amdgcn_ballot_w64(!fast && pos < stop && pos < total_bits) != 0) {
+					break;
+				}
+				if (fast) {
+					symbol();
+				}
+			}
+		}
+		// ---- careful: one symbol for the lanes that wait for it
+		if (pos >= fs && pos < stop && pos < total_bits) {
+			primed = false;
+			const uint32_t info = tb.info[c];
+			const bool isdc = z == 0;
+			const unsigned char *tb1 = luts + (((info >> (isdc ? 0 : 12)) & 0xfffu) << 4);
+			const uint32_t wj = pos >> 5;
+			const uint32_t wn = bit_window(S.word(wj), S.word(wj + 1), pos);
+			unsigned e1 = reinterpret_cast<const uint16_t *>(tb1)[wn >> (32 - JH_LUT_BITS)];
+			if (e1 & 0x8000u) {
+				e1 = long_code(tb1, e1, wn, isdc);
+			}
+			const int total = (int)(e1 >> 10), run = (int)((e1 >> 4) & 63u), cat = (int)(e1 & 15u);
+			const uint32_t npos = pos + (uint32_t)total;
+			if (e1 == 0 || npos > seg_end) {
+				// no code matches (the reference reads on to the end of the segment), or the data of this
+				// restart segment is used up (padding bits, truncated data): decoder.c:376-381.
+				// The MCU in progress is dropped (context->mblocks is not incremented), the next segment
+				// starts with block 0 / DC predictors 0 (decoder.c:369-373).
+				nb -= c;
+				c = 0;
+				z = 0;
+				st.reset = 1;
+#pragma unroll
+				for (int k = 0; k < JH_MAX_COMP; ++k) {
+					DCS_AT(dcs, k, dcs_stride) = 0;
+				}
+				st.seg++;
+				if (st.seg >= nseg) {
+					pos = total_bits;                  // the lane is done
+				} else {
+					pos = seg_end;
+					seg_end = min(seg_start[st.seg + 1] * 8u, total_bits);
+				}
+			} else {
+				const unsigned extra = __builtin_amdgcn_ubfe(wn, 32u - (unsigned)total, (unsigned)cat);
+				const int val = extend_sign(extra, cat);
+				if (isdc) {
+					atomicAdd(dcs + (info >> 24) * dcs_stride, val);
+				}
+				const int k = z + run;
+				pos = npos;
+				z = k + 1;
+				if (k >= 63) {
+					z = 0;
+					c = (c + 1 == B) ? 0 : c + 1;
+					nb++;
+				}
+			}
+		}
+	}
+	st.pos = pos;
+	st.c = c;
+	st.z = z;
+	st.nb = nb;
+#pragma unroll
+	for (int k = 0; k < JH_MAX_COMP; ++k) {
+		st.dc[k] = DCS_AT(dcs, k, dcs_stride);
+	}
+}
+
+// The same with the fast symbols as an inner loop of each lane and the careful path as its tail: the form for
+// streams of ONE restart segment (what is alive in the inner loop is dead in the tail, which leaves the
+// synchronisation kernels at 43 instead of 74 vector registers, 8 instead of 6 waves per SIMD).  Right for any
+// stream; slow on segmented ones for the reason given above.
+template <class Stream>
+__device__ __forceinline__ void decode_span_plain(DecState &st, const uint32_t stop, const Stream &S,
+                                            const uint32_t total_bits, const uint32_t *seg_start,
+                                            const uint32_t nseg, const unsigned char *luts,
+                                            const DecTables &tb, const int B, int *dcs, const int dcs_stride,
+                                            int16_t *coefs, int blk, const int nblk)
+{
+	constexpr bool WRITE = false;                          // the write pass is k_huff_write
 	if (st.pos >= stop || st.pos >= total_bits) {
 		return;
 	}
@@ -322,6 +503,22 @@ __device__ __forceinline__ void decode_span(DecState &st, const uint32_t stop, c
 #pragma unroll
 	for (int k = 0; k < JH_MAX_COMP; ++k) {
 		st.dc[k] = DCS_AT(dcs, k, dcs_stride);
+	}
+}
+
+
+// SEGMENTED: which form (a hint from the headers -- DRI -- not a promise: both are right for every stream)
+template <bool SEGMENTED, class Stream>
+__device__ __forceinline__ void decode_span(DecState &st, const uint32_t stop, const Stream &S,
+                                            const uint32_t total_bits, const uint32_t *seg_start,
+                                            const uint32_t nseg, const unsigned char *luts,
+                                            const DecTables &tb, const int B, int *dcs, const int dcs_stride,
+                                            int16_t *coefs, int blk, const int nblk)
+{
+	if (SEGMENTED) {
+		decode_span_segmented(st, stop, S, total_bits, seg_start, nseg, luts, tb, B, dcs, dcs_stride, coefs, blk, nblk);
+	} else {
+		decode_span_plain(st, stop, S, total_bits, seg_start, nseg, luts, tb, B, dcs, dcs_stride, coefs, blk, nblk);
 	}
 }
 

@@ -274,6 +274,7 @@ __device__ __forceinline__ bool rec_garbage(const JhSubInfo &r, uint32_t total_b
 	return next_sub < nsub && (pos >= total_bits || pos >= (next_sub + 1u) * JH_SUBSEQ_BITS);
 }
 
+template <bool SEGMENTED>
 __global__ __launch_bounds__(256) void k_huff_chains(const HuffArgs a)
 {
 	extern __shared__ __align__(16) unsigned char smem[];
@@ -307,7 +308,7 @@ __global__ __launch_bounds__(256) void k_huff_chains(const HuffArgs a)
 	DecState st;
 	state_from(st, (unsigned long long)t * JH_SUBSEQ_BITS, 0);
 	st.seg = nseg > 1 ? find_segment(seg_start, nseg, st.pos >> 3) : 0u;
-	decode_span<false>(st, (t + 1) * JH_SUBSEQ_BITS, S, total_bits, seg_start, nseg, luts, tb, a.g.B, mydcs, 256, nullptr, 0, 0);
+	decode_span<SEGMENTED>(st, (t + 1) * JH_SUBSEQ_BITS, S, total_bits, seg_start, nseg, luts, tb, a.g.B, mydcs, 256, nullptr, 0, 0);
 	store_info(&rec[0], st);
 	if (st.pos >= total_bits || st.pos >= (t + 2) * JH_SUBSEQ_BITS || t + 1 >= nsub) {
 		return;                            // garbage (rec_garbage: k_huff_links restarts with the next chain's guess), or the last one
@@ -316,7 +317,7 @@ __global__ __launch_bounds__(256) void k_huff_chains(const HuffArgs a)
 	const unsigned long long ps = pack_state(st);
 	const uint32_t sg = st.seg;
 	state_from(st, ps, sg);
-	decode_span<false>(st, (t + 2) * JH_SUBSEQ_BITS, S, total_bits, seg_start, nseg, luts, tb, a.g.B, mydcs, 256, nullptr, 0, 0);
+	decode_span<SEGMENTED>(st, (t + 2) * JH_SUBSEQ_BITS, S, total_bits, seg_start, nseg, luts, tb, a.g.B, mydcs, 256, nullptr, 0, 0);
 	store_info(&rec[1], st);
 }
 
@@ -369,6 +370,7 @@ __global__ __launch_bounds__(256) void k_huff_links(const HuffArgs a)
 	}
 }
 
+template <bool SEGMENTED>
 __global__ __launch_bounds__(256) void k_huff_survivors(const HuffArgs a)
 {
 	extern __shared__ __align__(16) unsigned char smem[];
@@ -406,7 +408,7 @@ __global__ __launch_bounds__(256) void k_huff_survivors(const HuffArgs a)
 		const uint32_t jl = i + d;         // < nsub
 		DecState st;
 		state_from(st, ps, sg);
-		decode_span<false>(st, (jl + 1) * JH_SUBSEQ_BITS, S, total_bits, seg_start, nseg, luts, tb, a.g.B, mydcs, 256, nullptr, 0, 0);
+		decode_span<SEGMENTED>(st, (jl + 1) * JH_SUBSEQ_BITS, S, total_bits, seg_start, nseg, luts, tb, a.g.B, mydcs, 256, nullptr, 0, 0);
 		store_info(&rec[d], st);
 		meta = d;
 		if ((st.pos >= total_bits || st.pos >= (jl + 2u) * JH_SUBSEQ_BITS) && jl + 1 < nsub) {
@@ -618,7 +620,7 @@ __device__ __forceinline__ JhSubInfo walk_step(const WalkCtx &c, unsigned long l
 		if (st.c >= c.B || st.z > 63 || st.seg >= c.nseg) {
 			st.pos = c.total_bits;             // cannot happen for states produced by decode_span
 		}
-		decode_span<false>(st, (q + 1) * JH_SUBSEQ_BITS, RegStream{c.cs}, c.total_bits, c.seg_start, c.nseg, luts, tb, c.B, dcs, 64,
+		decode_span<true>(st, (q + 1) * JH_SUBSEQ_BITS, RegStream{c.cs}, c.total_bits, c.seg_start, c.nseg, luts, tb, c.B, dcs, 64,
 		                   nullptr, 0, 0);
 		store_info(bcast, st);
 		*selfdec += 1;
@@ -855,7 +857,7 @@ __device__ void serial_walk(const HuffArgs &a, const JhDecFrame &fr, JhDecState 
 				if (st.c >= a.g.B || st.z > 63 || st.seg >= nseg) {
 					st.pos = total_bits;       // cannot happen for states produced by decode_span
 				}
-				decode_span<false>(st, (jn + 1) * JH_SUBSEQ_BITS, RegStream{cs}, total_bits, seg_start, nseg, luts, tb, a.g.B, dcs, 64, nullptr, 0, 0);
+				decode_span<true>(st, (jn + 1) * JH_SUBSEQ_BITS, RegStream{cs}, total_bits, seg_start, nseg, luts, tb, a.g.B, dcs, 64, nullptr, 0, 0);
 				store_info(&R, st);
 			}
 		}
@@ -978,13 +980,21 @@ int jh_launch_huff_sync(const JhDecodeWork &w, const JhGeom &g, hipStream_t s, c
 	const unsigned nwg = jh_num_chain_wgs(w.max_subs);
 	const unsigned nblk = (w.max_subs + 255u) / 256u;
 	JH_T_BEGIN(th, "k_huff_chains", s);
-	hipLaunchKernelGGL(k_huff_chains, dim3(nblk, w.nframes), dim3(256), lds, s, a);
+	if (w.segmented) {
+		hipLaunchKernelGGL(k_huff_chains<true>, dim3(nblk, w.nframes), dim3(256), lds, s, a);
+	} else {
+		hipLaunchKernelGGL(k_huff_chains<false>, dim3(nblk, w.nframes), dim3(256), lds, s, a);
+	}
 	JH_T_END(th, s);
 	JH_T_BEGIN(th, "k_huff_links", s);
 	hipLaunchKernelGGL(k_huff_links, dim3(nblk, w.nframes), dim3(256), 0, s, a);
 	JH_T_END(th, s);
 	JH_T_BEGIN(th, "k_huff_survivors", s);
-	hipLaunchKernelGGL(k_huff_survivors, dim3(nblk, w.nframes), dim3(256), lds, s, a);
+	if (w.segmented) {
+		hipLaunchKernelGGL(k_huff_survivors<true>, dim3(nblk, w.nframes), dim3(256), lds, s, a);
+	} else {
+		hipLaunchKernelGGL(k_huff_survivors<false>, dim3(nblk, w.nframes), dim3(256), lds, s, a);
+	}
 	JH_T_END(th, s);
 	JH_T_BEGIN(th, "k_huff_emit", s);
 	hipLaunchKernelGGL(k_huff_emit, dim3(nwg, w.nframes), dim3(256), 0, s, a);

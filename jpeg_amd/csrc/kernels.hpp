@@ -93,6 +93,8 @@ struct JhDecodeWork {             // device pointers of one decoder batch
 	uint32_t max_subs;            // per frame (grid size)
 	uint32_t max_luts;            // Huffman tables of the frame that uses most (LDS size)
 	int debug;                    // bit 0: force repairs, bit 1: force the serial walk (tests)
+	int segmented;                // a frame of the batch announces restart intervals (DRI): which form of the decode loop the
+	                              // synchronisation kernels take (a hint; both are right for every stream)
 	JhRemap rm;
 };
 
