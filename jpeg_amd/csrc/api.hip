@@ -22,6 +22,8 @@
 #include "codestream.hpp"
 #include "kernels.hpp"
 
+#define JH_MAX_PASSES 8               // scans per frame the decoder takes (each is a pass of the Huffman kernels)
+
 #define HIPCHK(call)                                                                         \
 	do {                                                                                     \
 		hipError_t e_ = (call);                                                              \
@@ -237,6 +239,7 @@ struct jpeg_hip_decoder {
 	int debug = 0;
 	bool tolerant = false;
 	bool coefs_only = false;          // run() stops behind the Huffman passes (jpeg_hip_read_scan)
+	bool all_scans_tried = false;     // sync() has prepared this batch again with every scan found on the host
 	StageTimer timer;
 
 	// Device buffers only grow: a decoder that is prepared again with a batch of similar size (Motion
@@ -281,7 +284,7 @@ extern "C" int jpeg_hip_decoder_create(jpeg_hip_decoder **dec, int device)
 	}
 	jpeg_hip_decoder *d = new jpeg_hip_decoder();
 	d->device = device;
-	d->pass.reserve(JH_MAX_COMP);                          // addresses of the passes stay put (see cap)
+	d->pass.reserve(JH_MAX_PASSES);                        // addresses of the passes stay put (see cap)
 	memset(&d->g, 0, sizeof d->g);
 	if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&d->copy_stream, hipStreamNonBlocking) != hipSuccess ||
 	    hipEventCreateWithFlags(&d->uploaded, hipEventDisableTiming) != hipSuccess ||
@@ -349,7 +352,8 @@ struct ScanDesc {
 // without them.
 enum { PARSE_SPLICE = 0x7fff0001 };
 
-static int parse_frame(const uint8_t *p, size_t n, JhHeader *h, std::vector<ScanDesc> *scans, bool tolerant, size_t *cut = nullptr)
+static int parse_frame(const uint8_t *p, size_t n, JhHeader *h, std::vector<ScanDesc> *scans, bool tolerant, size_t *cut = nullptr,
+                       bool all_scans = false)
 {
 	scans->clear();
 	int err = jh_parse_headers(p, n, h, tolerant);
@@ -380,26 +384,21 @@ static int parse_frame(const uint8_t *p, size_t n, JhHeader *h, std::vector<Scan
 		}
 		return RET_SUCCESS;
 	}
-	if (h->Ns == h->g.ncomp) {
-		// one scan with every component: the device finds its end (no host pass over the data)
+	if (h->Ns == h->g.ncomp && !all_scans) {
+		// One scan with every component: the device finds its end (no host pass over the data).  Should another
+		// scan follow it, sync() sees that and prepares the batch once more with all_scans set.
 		for (int j = 0; j < h->Ns; ++j) {
 			h->g.scan_order[j] = h->scan_comp[j];
 		}
 		describe(-1, n);
 		return RET_SUCCESS;
 	}
-	// several scans, each with one component or some of them
-	unsigned seen = 0;
-	for (;;) {
-		if (h->Ns >= h->g.ncomp) {
+	// Several scans, each with one component, some of them, or all: every scan is a pass over its own data in the
+	// file's order, and a component that is coded again is written again (read_block() stores every coefficient
+	// of a block it reads, coeffs.c:222-229; decoder.c:593-601 asks no questions).
+	for (int nscan = 0;; ++nscan) {
+		if (nscan >= JH_MAX_PASSES) {
 			return RET_FAILURE_FILE_UNSUPPORTED;
-		}
-		for (int j = 0; j < h->Ns; ++j) {
-			const int k = h->scan_comp[j];
-			if (seen & (1u << k)) {
-				return RET_FAILURE_FILE_UNSUPPORTED;       // a component coded twice
-			}
-			seen |= 1u << k;
 		}
 		const int k = h->Ns == 1 ? h->scan_comp[0] : -2;
 		const size_t end = jh_ecs_end(p, n, h->ecs_offset);
@@ -551,7 +550,7 @@ static int decoder_prepare(jpeg_hip_decoder *dec, int nframes, const uint8_t *co
 	dec->raw_bytes = raw_off + 4096;
 	const JhGeom &G = dec->g;
 
-	if (pass_comp.size() > (size_t)JH_MAX_COMP) {
+	if (pass_comp.size() > (size_t)JH_MAX_PASSES) {
 		return RET_FAILURE_FILE_UNSUPPORTED;
 	}
 	while (dec->pass.size() > pass_comp.size()) {
@@ -863,12 +862,9 @@ static int decoder_prepare(jpeg_hip_decoder *dec, int nframes, const uint8_t *co
 	return RET_SUCCESS;
 }
 
-extern "C" int jpeg_hip_decoder_prepare(jpeg_hip_decoder *dec, int nframes,
-                                        const uint8_t *const *jpg, const size_t *jpg_len)
+// all_scans: every scan is found on the host, also where the first one holds every component (see parse_frame)
+static int prepare_staged(jpeg_hip_decoder *dec, int nframes, const uint8_t *const *jpg, const size_t *jpg_len, bool all_scans)
 {
-	if (!dec || nframes <= 0 || !jpg || !jpg_len) {
-		return RET_FAILURE_LOGIC_ERROR;
-	}
 	std::vector<const uint8_t *> file(jpg, jpg + nframes);
 	std::vector<size_t> file_len(jpg_len, jpg_len + nframes);
 	std::vector<std::vector<uint8_t>> patched(nframes);    // damaged files with several scans, see parse_frame()
@@ -876,7 +872,7 @@ extern "C" int jpeg_hip_decoder_prepare(jpeg_hip_decoder *dec, int nframes,
 		int err = RET_FAILURE_FILE_UNSUPPORTED;
 		for (int tries = 0; tries < 64; ++tries) {
 			size_t cut[2] = {0, 0};
-			err = parse_frame(file[f], file_len[f], h, sc, dec->tolerant, cut);
+			err = parse_frame(file[f], file_len[f], h, sc, dec->tolerant, cut, all_scans);
 			if (err != PARSE_SPLICE) {
 				return err;
 			}
@@ -892,12 +888,23 @@ extern "C" int jpeg_hip_decoder_prepare(jpeg_hip_decoder *dec, int nframes,
 	});
 }
 
+extern "C" int jpeg_hip_decoder_prepare(jpeg_hip_decoder *dec, int nframes,
+                                        const uint8_t *const *jpg, const size_t *jpg_len)
+{
+	if (!dec || nframes <= 0 || !jpg || !jpg_len) {
+		return RET_FAILURE_LOGIC_ERROR;
+	}
+	dec->all_scans_tried = false;
+	return prepare_staged(dec, nframes, jpg, jpg_len, false);
+}
+
 extern "C" int jpeg_hip_decoder_prepare_pinned(jpeg_hip_decoder *dec, int nframes,
                                                const uint8_t *const *jpg, const size_t *jpg_len)
 {
 	if (!dec || nframes <= 0 || !jpg || !jpg_len) {
 		return RET_FAILURE_LOGIC_ERROR;
 	}
+	dec->all_scans_tried = false;
 	bool pinned = true, patch = false;
 	int err = decoder_prepare(dec, nframes, jpg, jpg_len, [&](int f, JhHeader *h, std::vector<ScanDesc> *sc) {
 		size_t cut[2] = {0, 0};
@@ -1101,6 +1108,7 @@ extern "C" int jpeg_hip_decoder_sync(jpeg_hip_decoder *dec, int *frame_status)
 		HIPCHK(hipEventSynchronize(dec->done));
 	}
 	int worst = RET_SUCCESS;
+	bool more_scans = false;
 	for (int f = 0; f < dec->nframes; ++f) {
 		int st = dec->parse_err[f];
 		dec->ecs_len[f] = 0;
@@ -1129,6 +1137,8 @@ extern "C" int jpeg_hip_decoder_sync(jpeg_hip_decoder *dec, int *frame_status)
 					const int e = jh_parse_next_scan(file, len, ds.term_pos - dec->file_off[f], &h1, &eoi);
 					if (e == RET_SUCCESS && eoi && memcmp(h0.Q, h1.Q, sizeof h0.Q) == 0) {
 						st = RET_SUCCESS;
+					} else if (e == RET_SUCCESS && !eoi) {
+						more_scans = true;               // another SOS: the components are coded again (decoder.c:593-601)
 					} else if (e == RET_FAILURE_FILE_IO) {
 						st = e;                          // no EOI behind it: read_marker() meets the end of the file
 					}
@@ -1141,6 +1151,37 @@ extern "C" int jpeg_hip_decoder_sync(jpeg_hip_decoder *dec, int *frame_status)
 		if (st && !worst) {
 			worst = st;
 		}
+	}
+	if (more_scans && !dec->all_scans_tried && !dec->coefs_only) {
+		// A frame whose first scan holds every component goes on with another scan.  prepare() left the end of that
+		// first scan to the device; now the host walks the files scan by scan and the batch is decoded again, one
+		// pass per scan (frames of the batch that differ in their scans are refused, as always).
+		dec->all_scans_tried = true;
+		const int n = dec->nframes;
+		std::vector<std::vector<uint8_t>> copy(n);
+		std::vector<const uint8_t *> ptr(n);
+		std::vector<size_t> len(n);
+		for (int f = 0; f < n; ++f) {
+			if (dec->file_ptr[f]) {
+				copy[f].assign(dec->file_ptr[f], dec->file_ptr[f] + dec->file_len[f]);   // the staging buffer is about to be refilled
+			}
+			ptr[f] = copy[f].data();
+			len[f] = copy[f].size();
+		}
+		void *out = dec->last_out;
+		const size_t stride = dec->last_stride;
+		hipStream_t s = dec->last_stream;
+		int err = prepare_staged(dec, n, ptr.data(), len.data(), true);
+		if (!err) {
+			err = jpeg_hip_decoder_run(dec, out, stride, s);
+		}
+		if (err) {
+			for (int f = 0; frame_status && f < n; ++f) {
+				frame_status[f] = err;
+			}
+			return err;
+		}
+		return jpeg_hip_decoder_sync(dec, frame_status);
 	}
 	return worst;
 }

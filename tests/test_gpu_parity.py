@@ -670,3 +670,99 @@ def test_noise_at_top_quality_outgrows_the_stream_buffers(hip, oracle, P, opt):
         ac = hip.htables([oracle.default_table(1, 0)] + [None] * 3)
         err, ecs = hip.write_scan(fd, sd, dc, ac, 0, [info.comps[0]["coef"]])
         assert err == 0 and ecs in want
+
+
+def _scan_segments(jpg):
+    """(start of SOS marker, end of its entropy-coded data) of every scan of a file"""
+    out = []
+    i = 2
+    while i + 3 < len(jpg):
+        assert jpg[i] == 0xFF, i
+        m = jpg[i + 1]
+        if m == 0xD9:
+            break
+        ln = (jpg[i + 2] << 8) | jpg[i + 3]
+        if m != 0xDA:
+            i += 2 + ln
+            continue
+        j = i + 2 + ln
+        while not (jpg[j] == 0xFF and jpg[j + 1] != 0 and not 0xD0 <= jpg[j + 1] <= 0xD7):
+            j += 1
+        out.append((i, j))
+        i = j
+    return out
+
+
+def test_components_coded_more_than_once(hip, oracle):
+    """decoder.c:593-601 reads whatever scans come; read_block() stores every coefficient of a block it reads
+    (coeffs.c:222-229), so a component that is coded again is simply written again.  Files made by splicing scans
+    of a second image (same size, same tables) into the first: luma twice, all components again behind the
+    per-component scans, a group of two behind them, restart intervals on and off."""
+    a = synth_image(176, 112, 3, 8, seed=41)
+    b = synth_image(176, 112, 3, 8, seed=42)
+    for ri in (0, 5):
+        err, ja = oracle.encode_scans(a, P=8, H=2, V=2, q=80, optimize=0, restart_interval=ri, redefine=0, split=0)
+        err2, jb = oracle.encode_scans(b, P=8, H=2, V=2, q=80, optimize=0, restart_interval=ri, redefine=0, split=0)
+        err3, jb1 = oracle.encode_scans(b, P=8, H=2, V=2, q=80, optimize=0, restart_interval=ri, redefine=0, split=1)
+        err4, jfull, _ = oracle.encode(b, P=8, H=2, V=2, q=80, optimize=0, restart_interval=ri)
+        assert err == err2 == err3 == err4 == 0
+        sa, sb, sb1, sf = _scan_segments(ja), _scan_segments(jb), _scan_segments(jb1), _scan_segments(jfull)
+        assert len(sa) == 3 and len(sb) == 3 and len(sf) == 1
+        head, tail = ja[:sa[-1][1]], ja[sa[-1][1]:]
+        files = {
+            "luma twice": head + jb[sb[0][0]:sb[0][1]] + tail,
+            "all again": head + jfull[sf[0][0]:sf[0][1]] + tail,
+            "a group again": head + jb1[sb1[-1][0]:sb1[-1][1]] + tail,
+            "chroma first, luma twice": ja[:sa[0][0]] + ja[sa[1][0]:sa[2][1]] + ja[sa[0][0]:sa[0][1]] + jb[sb[0][0]:sb[0][1]] + tail,
+        }
+        for name, jpg in files.items():
+            oerr, opx, oinfo = oracle.decode(jpg)
+            assert oerr == 0, name
+            d = hip.Decoder()
+            d.prepare([jpg, jpg])
+            out = d.run()
+            assert d.sync() == [0, 0], (name, ri)
+            _assert_coefs(d.coefficients(1), oinfo)
+            for px in d.to_arrays(out):
+                assert np.array_equal(px, opx), (name, ri)
+            d.close()
+        assert not np.array_equal(oracle.decode(files["luma twice"])[1], oracle.decode(ja)[1])
+        # a first scan with every component and more scans behind it: prepare() leaves the end of such a scan to
+        # the device, sync() finds the SOS behind it and decodes the batch again scan by scan
+        err, jfa, _ = oracle.encode(a, P=8, H=2, V=2, q=80, optimize=0, restart_interval=ri)
+        sfa = _scan_segments(jfa)
+        again = {
+            "all, then luma": jfa[:sfa[0][1]] + jb[sb[0][0]:sb[0][1]] + jfa[sfa[0][1]:],
+            "all twice": jfa[:sfa[0][1]] + jfull[sf[0][0]:sf[0][1]] + jfa[sfa[0][1]:],
+        }
+        for name, jpg in again.items():
+            oerr, opx, oinfo = oracle.decode(jpg)
+            assert oerr == 0, name
+            for pinned in (False, True):
+                d = hip.Decoder()
+                src = hip.PinnedFrames.from_frames([jpg, jpg, jpg]) if pinned else [jpg, jpg, jpg]
+                d.prepare(src)
+                out = d.run()
+                assert d.sync() == [0, 0, 0], (name, ri, pinned)
+                _assert_coefs(d.coefficients(2), oinfo)
+                for px in d.to_arrays(out):
+                    assert np.array_equal(px, opx), (name, ri)
+                # the same decoder on ordinary frames afterwards
+                d.prepare([jfa])
+                out = d.run()
+                assert d.sync() == [0]
+                assert np.array_equal(d.to_arrays(out)[0], oracle.decode(jfa)[1])
+                d.close()
+        # gray, coded twice; and a batch in which only one frame has the second scan (that frame is refused)
+        ga, gb = synth_image(96, 64, 1, 8, seed=5), synth_image(96, 64, 1, 8, seed=6)
+        _, jga, _ = oracle.encode(ga, P=8, H=1, V=1, q=75, optimize=0, restart_interval=ri)
+        _, jgb, _ = oracle.encode(gb, P=8, H=1, V=1, q=75, optimize=0, restart_interval=ri)
+        sga, sgb = _scan_segments(jga), _scan_segments(jgb)
+        twice = jga[:sga[0][1]] + jgb[sgb[0][0]:sgb[0][1]] + jga[sga[0][1]:]
+        oerr, opx, _ = oracle.decode(twice)
+        assert oerr == 0 and np.array_equal(opx, oracle.decode(jgb)[1])
+        outs, st = hip.decode([twice])
+        assert st == [0] and np.array_equal(outs[0], opx)
+        outs, st = hip.decode([jga, twice, jgb])
+        assert st[0] == 0 and st[2] == 0 and st[1] == 0x1001
+        assert np.array_equal(outs[0], oracle.decode(jga)[1]) and np.array_equal(outs[2], oracle.decode(jgb)[1])

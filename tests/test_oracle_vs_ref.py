@@ -192,3 +192,48 @@ def test_data_that_runs_out_inside_an_mcu(oracle, reference):
             assert eo == er == 0
             assert _same_coefs(io, ir), (m, back)
             assert np.array_equal(po, pr)
+
+
+def _scan_segments(jpg):
+    """(start of SOS marker, end of its entropy-coded data) of every scan of a file"""
+    out = []
+    i = 2
+    while i + 3 < len(jpg):
+        m = jpg[i + 1]
+        if m == 0xD9:
+            break
+        ln = (jpg[i + 2] << 8) | jpg[i + 3]
+        if m != 0xDA:
+            i += 2 + ln
+            continue
+        j = i + 2 + ln
+        while not (jpg[j] == 0xFF and jpg[j + 1] != 0 and not 0xD0 <= jpg[j + 1] <= 0xD7):
+            j += 1
+        out.append((i, j))
+        i = j
+    return out
+
+
+def test_components_coded_more_than_once(oracle, reference):
+    """decoder.c:593-601 reads whatever scans come, and read_block() stores every coefficient of a block it reads
+    (coeffs.c:222-229): a component coded again is written again.  The oracle against the compiled reference on
+    files spliced from the scans of two images (the GPU test uses the same constructions)."""
+    a = synth_image(176, 112, 3, 8, seed=41)
+    b = synth_image(176, 112, 3, 8, seed=42)
+    for ri in (0, 5):
+        _, ja = oracle.encode_scans(a, P=8, H=2, V=2, q=80, optimize=0, restart_interval=ri, redefine=0, split=0)
+        _, jb = oracle.encode_scans(b, P=8, H=2, V=2, q=80, optimize=0, restart_interval=ri, redefine=0, split=0)
+        _, jfa, _ = oracle.encode(a, P=8, H=2, V=2, q=80, optimize=0, restart_interval=ri)
+        _, jfb, _ = oracle.encode(b, P=8, H=2, V=2, q=80, optimize=0, restart_interval=ri)
+        sa, sb, sfa, sfb = _scan_segments(ja), _scan_segments(jb), _scan_segments(jfa), _scan_segments(jfb)
+        files = [
+            ja[:sa[-1][1]] + jb[sb[0][0]:sb[0][1]] + ja[sa[-1][1]:],            # luma twice
+            ja[:sa[-1][1]] + jfb[sfb[0][0]:sfb[0][1]] + ja[sa[-1][1]:],         # every component again
+            jfa[:sfa[0][1]] + jb[sb[0][0]:sb[0][1]] + jfa[sfa[0][1]:],          # all, then luma
+            jfa[:sfa[0][1]] + jfb[sfb[0][0]:sfb[0][1]] + jfa[sfa[0][1]:],       # all twice
+        ]
+        for jpg in files:
+            eo, po, io = oracle.decode(jpg)
+            er, pr, ir = reference.decode(jpg)
+            assert eo == er == 0
+            assert _same_coefs(io, ir) and np.array_equal(po, pr)
