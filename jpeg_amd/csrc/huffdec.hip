@@ -681,13 +681,15 @@ __global__ __launch_bounds__(WR_THREADS) void k_huff_write(const HuffArgs a)
 					// The next segment's blocks go to the same places, stored by other threads: k_huff_fixup settles
 					// the order afterwards.  Recorded by the thread in whose sub-sequence the segment ends.
 					const bool partial = z != 0;
-					if (pos < stop && (c != 0 || partial)) {
+					// (pos >= total_bits: the thread is past its sub-sequence and no other starts behind the data)
+					if ((pos < stop || pos >= total_bits) && (c != 0 || partial)) {
 						if (seg + 1 < nseg) {
 							w.drop[fr.seg_off + seg + 1] = ((unsigned long long)(uint32_t)(blk - c) << 8) | (unsigned)(c + (partial ? 1 : 0));
 							atomicAdd(&w.state[f].ndrop, 1u);
-						} else {
-							atomicMax(&w.state[f].ntail, (uint32_t)max(blk + (partial ? 1 : 0), 0));
 						}
+						// what is left of the MCU stays unless a later segment stores over it (none may: the last
+						// segment, or segments that do not get as far): k_coef_tail_clear keeps off
+						atomicMax(&w.state[f].ntail, (uint32_t)max(blk + (partial ? 1 : 0), 0));
 					}
 					if (partial) {
 						mybuf[rot] -= (int16_t)lastold;             // coefficient 0
@@ -738,6 +740,12 @@ __global__ __launch_bounds__(WR_THREADS) void k_huff_write(const HuffArgs a)
 			}
 		}
 		flush_blocks(fin, fblk, bufs, frame_coefs, pack);
+	}
+	// The data of the LAST segment may end exactly behind a block that is not the last of its MCU, and behind this
+	// thread's sub-sequence: no thread starts there (there is no bit left), so nobody meets the end of the segment.
+	// The blocks of that unfinished MCU stay (decoder.c:347-355): say so before k_coef_tail_clear asks.
+	if ((fl & F_ACT) && z == 0 && c != 0 && pos >= total_bits) {
+		atomicMax(&w.state[f].ntail, (uint32_t)max(blk, 0));
 	}
 }
 

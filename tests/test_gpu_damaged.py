@@ -231,7 +231,41 @@ def test_markers_inside_the_data_followed_by_restart_intervals(hip, oracle):
     assert _compare(hip, oracle, jpg1[:at] + dht + jpg1[at:], "dht") == "tables behind a stray marker"
 
 
-@pytest.mark.parametrize("seed", [7, 11, 2024])
+def test_streams_the_fuzz_runs_found(hip, oracle):
+    """tests/golden/damaged/: streams of tools/fuzz_corrupt.py (seeds 22 and 23) on which the write pass lost the
+    blocks of an unfinished MCU to k_coef_tail_clear -- data that ends exactly where a sub-sequence does, and a
+    spurious RSTn whose segment holds nothing decodable behind a segment that ended inside a block."""
+    import glob
+    import os
+    files = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "damaged", "*.jpg")))
+    assert len(files) >= 3
+    for path in files:
+        with open(path, "rb") as fh:
+            assert _compare(hip, oracle, fh.read(), os.path.basename(path)) is None
+
+
+def test_data_that_ends_where_a_sub_sequence_ends(hip, oracle):
+    """The unstuffed data is cut to whole multiples of 256 bytes (the decoder's sub-sequences): the thread that
+    meets the end is then past its own sub-sequence and no thread starts behind it."""
+    img = synth_image(320, 200, 3, 8, seed=13)
+    for H, V in ((2, 1), (1, 1), (2, 2)):
+        err, jpg, _ = oracle.encode(img, P=8, H=H, V=V, q=88, optimize=0)
+        start = _ecs_start(jpg)
+        body = jpg[start:-2]
+        for nsub in (3, 8, 20, 21):
+            # walk the stuffed bytes until nsub * 256 payload bytes are behind us
+            kept, i = 0, 0
+            while kept < nsub * 256 and i < len(body):
+                i += 2 if body[i] == 0xFF else 1
+                kept += 1
+            for extra in (0, 1):
+                bad = jpg[:start] + body[:i + extra] + b"\xff\xd9"
+                if bad[-3] == 0xFF:
+                    continue
+                assert _compare(hip, oracle, bad, ("boundary", H, V, nsub, extra)) is None
+
+
+@pytest.mark.parametrize("seed", [7, 11, 2024, 22, 23])
 def test_fixed_seed_fuzz(hip, oracle, seed):
     """300 damaged streams per seed: identical to the oracle, or claimed by a named deviation (counted and
     bounded: they are rare)."""
