@@ -63,7 +63,9 @@ def _first_stray_marker(bad):
 def _tables_behind_a_stray_marker(bad, st, oerr):
     """D1: the scan was ended by a marker that is neither RSTn nor EOI, and a table, frame or scan header comes
     before the next RSTn/EOI.  The reference reads it and goes on with the changed tables; the GPU path made its
-    decoding tables when the scan started and reports FILE_UNSUPPORTED (0x1001) for the frame."""
+    decoding tables when the scan started and reports FILE_UNSUPPORTED (0x1001) for the frame.  In files of
+    several scans the same happens behind a damaged DHT or SOS segment: the reference reads past it, skips to the
+    next marker, and decodes the restart intervals it finds there as more of the scan before."""
     if st != 0x1001 or oerr != 0:
         return False
     at = _first_stray_marker(bad)
@@ -93,6 +95,10 @@ def _compare(hip, oracle, bad, what):
             st, out = e.code, None
         if st == oerr:
             if st == 0:
+                if max(int(np.abs(c["coef"]).max()) for c in oinfo.comps) > 32767:
+                    # D4: garbage whose DC differences add up past 16 bits: the reference keeps int32 coefficients
+                    # (coeffs.h:9-11), this path int16 -- no codestream of an image gets there
+                    return "coefficients beyond 16 bits"
                 for k, (a, c) in enumerate(zip(d.coefficients(0), oinfo.comps)):
                     df = np.nonzero((a != c["coef"]).any(axis=1))[0]
                     assert len(df) == 0, "%s: component %d, %d blocks differ, first %d" % (what, k, len(df), df[0])
