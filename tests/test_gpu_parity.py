@@ -580,6 +580,39 @@ def test_frames_in_page_locked_memory(hip, oracle):
     good.buf.close()
 
 
+def test_pinned_frames_scattered_over_memory(hip, oracle):
+    """jpeg_hip_decoder_prepare_pinned with frames in different page-locked buffers, far apart or in descending
+    order: a span that is mostly holes falls back to the staged path; either way the samples are the oracle's."""
+    import ctypes as C
+    frames = []
+    for i in range(3):
+        img = synth_image(120, 88, 3, 8, seed=700 + i)
+        err, j, _ = oracle.encode(img, P=8, H=2, V=1, q=70 + i, optimize=1)
+        assert err == 0
+        frames.append(j)
+    bufs = [hip.PinnedBuffer(64 << 20), hip.PinnedBuffer(len(frames[1]) + 100), hip.PinnedBuffer(1 << 20)]
+    offs = [(48 << 20) + 3, 7, 4096]
+    for b, o, j in zip(bufs, offs, frames):
+        C.memmove(b.addr + o, j, len(j))
+    for order in ((0, 1, 2), (2, 1, 0), (1, 0), (0,)):
+        n = len(order)
+        ptrs = (C.c_void_p * n)(*[bufs[k].addr + offs[k] for k in order])
+        lens = (C.c_size_t * n)(*[len(frames[k]) for k in order])
+        d = hip.Decoder()
+        assert d.L.jpeg_hip_decoder_prepare_pinned(d.h, n, ptrs, lens) == 0
+        d.n = n
+        d.info = hip.FrameInfo()
+        d.L.jpeg_hip_decoder_info(d.h, C.byref(d.info))
+        d.frame_bytes = d.L.jpeg_hip_decoder_frame_bytes(d.h)
+        out = d.run()
+        assert d.sync() == [0] * n
+        for px, k in zip(d.to_arrays(out), order):
+            assert np.array_equal(px, oracle.decode(frames[k])[1]), order
+        d.close()
+    for b in bufs:
+        b.close()
+
+
 def test_markers_the_reference_rejects(hip, oracle):
     """APP9 / APP10 / APP15 / DNL end the reference's parse_format() with "unhandled marker"
     (decoder.c:654-656): the default is the same status; set_tolerant() skips such segments."""
