@@ -22,12 +22,21 @@ int main(int argc, char **argv)
 		fclose(f);
 		size_t sos = 0;
 		for (size_t i = 0; i + 1 < d.size(); ++i) if (d[i] == 0xff && d[i + 1] == 0xda) { sos = i; break; }
-		for (int it = 0; it < 4000; ++it) {
+		const int iters = getenv("HOST_SAN_ITERS") ? atoi(getenv("HOST_SAN_ITERS")) : 4000;
+		for (int it = 0; it < iters; ++it) {
 			std::vector<uint8_t> b(d);
 			const int k = 1 + rnd() % 3;
 			for (int j = 0; j < k; ++j) {
 				size_t p = 2 + rnd() % (sos + 12);
 				b[p] = (rnd() & 1) ? (uint8_t)rnd() : (uint8_t)(b[p] ^ (1u << (rnd() % 8)));
+			}
+			if (rnd() % 2 == 0 && b.size() > sos + 40) {
+				for (int j = 0; j < 3; ++j) {
+					size_t p = sos + 20 + rnd() % (b.size() - sos - 24);
+					static const uint8_t mk[] = {0x01, 0xd8, 0xe1, 0xfe, 0xdd, 0xd3, 0xc4, 0xdb, 0xd9, 0xcc};
+					b[p] = 0xff;
+					b[p + 1] = mk[rnd() % sizeof mk];
+				}
 			}
 			if (rnd() % 8 == 0) b.resize(2 + rnd() % b.size());
 			// exact-size heap copy so that any over-read is caught
@@ -51,6 +60,13 @@ int main(int argc, char **argv)
 					size_t end = jh_ecs_end(h, b.size(), hd.ecs_offset);
 					bool eoi = false;
 					if (end < b.size()) jh_parse_next_scan(h, b.size(), end, &hd, &eoi);
+					// the walk sync() makes behind a stray marker, from anywhere in the data
+					for (int j = 0; j < 8; ++j) {
+						size_t rst = 0;
+						const size_t pos = hd.ecs_offset + rnd() % (b.size() - hd.ecs_offset + 1);
+						const int e = jh_walk_to_restart(h, b.size(), pos, (rnd() & 1) != 0, &rst);
+						if (e == 0 && rst && (rst < pos || rst + 1 >= b.size() || h[rst] != 0xff)) abort();
+					}
 				}
 			}
 			size_t off[8], len[8];
