@@ -187,6 +187,7 @@ struct DecPass {
 	JhSubInfo *d_rec = nullptr, *d_prec = nullptr;
 	unsigned long long *d_wg_key = nullptr;
 	uint32_t *d_meta = nullptr, *d_surv = nullptr;
+	unsigned long long *d_key01 = nullptr;
 	JhWgAgg *d_wg_agg = nullptr, *d_wg_base = nullptr;
 	JhSubStart *d_start = nullptr;
 	unsigned long long *d_drop = nullptr;
@@ -203,11 +204,11 @@ struct DecPass {
 	{
 		hipFree(d_cs); hipFree(d_seg); hipFree(d_chunk_kept); hipFree(d_chunk_rst);
 		hipFree(d_start); hipFree(d_frames); hipFree(d_state); hipFree(d_luts);
-		hipFree(d_rec); hipFree(d_meta); hipFree(d_surv); hipFree(d_wg_agg); hipFree(d_wg_base); hipFree(d_prec); hipFree(d_wg_key); hipFree(d_drop);
+		hipFree(d_rec); hipFree(d_meta); hipFree(d_surv); hipFree(d_key01); hipFree(d_wg_agg); hipFree(d_wg_base); hipFree(d_prec); hipFree(d_wg_key); hipFree(d_drop);
 		d_drop = nullptr;
 		d_cs = nullptr; d_seg = d_chunk_kept = d_chunk_rst = nullptr;
 		d_start = nullptr; d_frames = nullptr; d_state = nullptr; d_luts = nullptr;
-		d_rec = d_prec = nullptr; d_meta = nullptr; d_surv = nullptr; d_wg_agg = d_wg_base = nullptr; d_wg_key = nullptr;
+		d_rec = d_prec = nullptr; d_meta = nullptr; d_surv = nullptr; d_key01 = nullptr; d_wg_agg = d_wg_base = nullptr; d_wg_key = nullptr;
 	}
 };
 
@@ -724,6 +725,7 @@ static int decoder_prepare(jpeg_hip_decoder *dec, int nframes, const uint8_t *co
 		HIPCHK(dec->grow((void **)&ps.d_rec, sub_entries * (JH_CHAIN_MAX + 1) * sizeof(JhSubInfo)));
 		HIPCHK(dec->grow((void **)&ps.d_meta, sub_entries * sizeof(uint32_t)));
 		HIPCHK(dec->grow((void **)&ps.d_surv, sub_entries * sizeof(uint32_t)));
+		HIPCHK(dec->grow((void **)&ps.d_key01, sub_entries * 2 * sizeof(unsigned long long)));
 		HIPCHK(dec->grow((void **)&ps.d_prec, sub_entries * sizeof(JhSubInfo)));
 		HIPCHK(dec->grow((void **)&ps.d_wg_key, wg_entries * sizeof(unsigned long long)));
 		HIPCHK(dec->grow((void **)&ps.d_wg_agg, wg_entries * sizeof(JhWgAgg)));
@@ -841,6 +843,7 @@ static int decoder_prepare(jpeg_hip_decoder *dec, int nframes, const uint8_t *co
 		w.rec = ps.d_rec;
 		w.meta = ps.d_meta;
 		w.surv = ps.d_surv;
+		w.key01 = ps.d_key01;
 		w.prec = ps.d_prec;
 		w.wg_key = ps.d_wg_key;
 		w.wg_agg = ps.d_wg_agg;

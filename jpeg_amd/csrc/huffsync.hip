@@ -268,9 +268,9 @@ __device__ __forceinline__ void store_agg(JhWgAgg *dst, const Agg &t, uint32_t e
 // guess takes over (restart link) -- and cheap to say: left alone, such a chain idles through its sixteen steps
 // towards that segment, links to nothing, and a workgroup range whose path starts with it has to be walked again
 // (with optimised tables, where many codes do not exist, one chain in a hundred is of this kind).
-__device__ __forceinline__ bool rec_garbage(const JhSubInfo &r, uint32_t total_bits, uint32_t next_sub, uint32_t nsub)
+__device__ __forceinline__ bool key_garbage(unsigned long long key, uint32_t total_bits, uint32_t next_sub, uint32_t nsub)
 {
-	const uint32_t pos = (uint32_t)(r.state & 0xffffffffu);
+	const uint32_t pos = (uint32_t)(key & 0xffffffffu);    // chain_key() and JhSubInfo.state alike
 	return next_sub < nsub && (pos >= total_bits || pos >= (next_sub + 1u) * JH_SUBSEQ_BITS);
 }
 
@@ -310,8 +310,11 @@ __global__ __launch_bounds__(256) void k_huff_chains(const HuffArgs a)
 	st.seg = nseg > 1 ? find_segment(seg_start, nseg, st.pos >> 3) : 0u;
 	decode_span<SEGMENTED>(st, (t + 1) * JH_SUBSEQ_BITS, S, total_bits, seg_start, nseg, luts, tb, a.g.B, mydcs, 256, nullptr, 0, 0);
 	store_info(&rec[0], st);
+	// the exit states once more, packed: what k_huff_links and k_huff_survivors compare (8 bytes instead of a line)
+	unsigned long long *key01 = w.key01 + (size_t)(fr.sub_off + t) * 2;
+	key01[0] = chain_key(pack_state(st), st.seg);
 	if (st.pos >= total_bits || st.pos >= (t + 2) * JH_SUBSEQ_BITS || t + 1 >= nsub) {
-		return;                            // garbage (rec_garbage: k_huff_links restarts with the next chain's guess), or the last one
+		return;                            // garbage (key_garbage: k_huff_links restarts with the next chain's guess), or the last one
 	}
 	// step 1: the next sub-sequence from where step 0 ended (sums counted anew)
 	const unsigned long long ps = pack_state(st);
@@ -319,6 +322,7 @@ __global__ __launch_bounds__(256) void k_huff_chains(const HuffArgs a)
 	state_from(st, ps, sg);
 	decode_span<SEGMENTED>(st, (t + 2) * JH_SUBSEQ_BITS, S, total_bits, seg_start, nseg, luts, tb, a.g.B, mydcs, 256, nullptr, 0, 0);
 	store_info(&rec[1], st);
+	key01[1] = chain_key(pack_state(st), st.seg);
 }
 
 __global__ __launch_bounds__(256) void k_huff_links(const HuffArgs a)
@@ -335,19 +339,19 @@ __global__ __launch_bounds__(256) void k_huff_links(const HuffArgs a)
 	}
 	bool survive = false;
 	if (t < nsub) {
-		const JhSubInfo *rec = w.rec + (size_t)(fr.sub_off + t) * (KMAX + 1);
-		const JhSubInfo r0 = rec[0];
+		const unsigned long long *key01 = w.key01 + (size_t)(fr.sub_off + t) * 2;
+		const unsigned long long k0 = key01[0];
 		uint32_t meta;                     // steps walked | link distance << 8 | restart link
-		if (rec_garbage(r0, total_bits, t + 1, nsub)) {
+		if (key_garbage(k0, total_bits, t + 1, nsub)) {
 			meta = 0u | (1u << 8) | META_RESTART;
 		} else if (t + 1 >= nsub) {
 			meta = 0u;
 		} else {
-			const JhSubInfo r1 = rec[1];
-			const JhSubInfo n0 = rec[KMAX + 1];            // the younger neighbour after its step 0
-			if (rec_garbage(r1, total_bits, t + 2, nsub)) {
+			const unsigned long long k1 = key01[1];
+			const unsigned long long n0 = key01[2];            // the younger neighbour after its step 0
+			if (key_garbage(k1, total_bits, t + 2, nsub)) {
 				meta = 1u | (2u << 8) | META_RESTART;
-			} else if (!rec_garbage(n0, total_bits, t + 2, nsub) && chain_key(r1.state, r1.seg) == chain_key(n0.state, n0.seg)) {
+			} else if (!key_garbage(n0, total_bits, t + 2, nsub) && k1 == n0) {
 				meta = 1u | (1u << 8);                     // same state as the younger chain: identical from here on
 			} else {
 				meta = 1u;
@@ -412,7 +416,7 @@ __global__ __launch_bounds__(256) void k_huff_survivors(const HuffArgs a)
 		store_info(&rec[d], st);
 		meta = d;
 		if ((st.pos >= total_bits || st.pos >= (jl + 2u) * JH_SUBSEQ_BITS) && jl + 1 < nsub) {
-			meta |= ((d + 1u) << 8) | META_RESTART;        // garbage (rec_garbage): restart with the next chain's guess
+			meta |= ((d + 1u) << 8) | META_RESTART;        // garbage (key_garbage): restart with the next chain's guess
 			break;
 		}
 		ps = pack_state(st);
@@ -421,17 +425,16 @@ __global__ __launch_bounds__(256) void k_huff_survivors(const HuffArgs a)
 		// Younger chains that were here in steps 0 and 1: chain jl (its own sub-sequence) and chain jl - 1.  Equal
 		// state = identical future.  Either of them has the record of sub-sequence jl + 1 if there is one: chain
 		// jl from its step 1; chain jl - 1, which did not coincide with chain jl or this chain would too, as a survivor.
-		const JhSubInfo *rj = w.rec + (size_t)(fr.sub_off + jl) * (KMAX + 1);
-		const JhSubInfo o0 = rj[0];
-		const JhSubInfo p0 = (rj - (KMAX + 1))[0];
+		const unsigned long long *kj = w.key01 + (size_t)(fr.sub_off + jl) * 2;
+		const unsigned long long o0 = kj[0], p0 = kj[-2];
 		uint32_t hit = 0;
-		if (!rec_garbage(p0, total_bits, jl, nsub)) {
-			const JhSubInfo p1 = (rj - (KMAX + 1))[1];
-			if (!rec_garbage(p1, total_bits, jl + 1, nsub) && chain_key(p1.state, p1.seg) == key) {
+		if (!key_garbage(p0, total_bits, jl, nsub)) {
+			const unsigned long long p1 = kj[-1];
+			if (!key_garbage(p1, total_bits, jl + 1, nsub) && p1 == key) {
 				hit = d - 1u;
 			}
 		}
-		if (!rec_garbage(o0, total_bits, jl + 1, nsub) && chain_key(o0.state, o0.seg) == key) {
+		if (!key_garbage(o0, total_bits, jl + 1, nsub) && o0 == key) {
 			hit = d;
 		}
 		if (hit) {

@@ -77,6 +77,7 @@ struct JhDecodeWork {             // device pointers of one decoder batch
 	uint32_t *chunk_kept, *chunk_rst;
 	JhSubInfo *rec;               // [sub-sequence t][step d <= JH_CHAIN_MAX]: chain t after sub-sequence t + d
 	uint32_t *meta;               // per chain: steps walked | (link distance << 8) | restarted-after-garbage << 31
+	unsigned long long *key01;    // [sub-sequence t][2]: chain_key of chain t after steps 0 and 1
 	uint32_t *surv;               // per frame (at sub_off): the chains listed by k_huff_links
 	JhSubInfo *prec;              // per sub-sequence: its record on the emitting workgroup's path (bit 63 of state: none)
 	unsigned long long *wg_key;   // per chains workgroup: the entry state its emitted records assume
