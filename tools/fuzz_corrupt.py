@@ -17,7 +17,7 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rnd = random.Random(seed)
 orc = Oracle()
-st_diff = px_diff = big = 0
+st_diff = px_diff = n_big = 0
 t0 = time.time()
 for case in range(N):
     bad, meta = corrupt_case(rnd, orc, seed, case)
@@ -45,10 +45,10 @@ for case in range(N):
         st_diff += 1
         print("STATUS", case, kind, hex(st & 0xffffffff), hex(oerr & 0xffffffff), meta)
     elif st == 0 and max(int(np.abs(c["coef"]).max()) for c in oinfo.comps) > 32767:
-        big += 1                                          # D4: int32 coefficients in the reference, int16 here
+        n_big += 1                                        # D4: int32 coefficients in the reference, int16 here
     elif st == 0 and not np.array_equal(px, opx):
         px_diff += 1
         frac = float((px != opx).any(axis=-1).mean()) if px.ndim == 3 else float((px != opx).mean())
         print("SAMPLES", case, kind, "differing pixels %.4f" % frac, meta, why)
 print("corrupt fuzz: %d cases, %d status differences, %d sample differences, %d with coefficients beyond 16 bits (not compared), %.0f s" % (
-    N, st_diff, px_diff, big, time.time() - t0))
+    N, st_diff, px_diff, n_big, time.time() - t0))
