@@ -17,8 +17,9 @@
 
 // ---- Huffman decode look-up ---------------------------------------------------------------
 #define JH_LUT_BITS 10                // fast table index width
-#define JH_SUBSEQ_BITS 2048           // bits per speculative sub-sequence (one thread each)
-#define JH_SUBSEQ_BYTES (JH_SUBSEQ_BITS / 8)
+#define JH_SUBSEQ_SHIFT 11            // log2 of the bits per speculative sub-sequence (one thread each): 2048 is the measured
+                                      // best for ordinary images; JhDecodeWork.sub_shift is what the kernels use (dense data: 12)
+#define JH_SUBSEQ_SHIFT_DENSE 12
 #define JH_CHAIN_MAX 16               // steps a speculative chain may walk before it is cut
 #define JH_SEQ_OWN (256 - JH_CHAIN_MAX)   // sub-sequences owned by one workgroup (the rest are ghosts)
 // chains workgroup b covers sub-sequences [b * OWN, b * OWN + 256) and EMITS the entry records of

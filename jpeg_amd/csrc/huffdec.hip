@@ -12,7 +12,7 @@
 //        byte offset at which every restart segment starts.  The ECS ends at the first FF xx with
 //        xx not in {00, D0..D7} (io.c:265-269).
 //   2. huffsync.hip: k_huff_chains / k_huff_walk / k_huff_finish
-//        the stream is cut into sub-sequences of JH_SUBSEQ_BITS bits, one thread each.  Every thread
+//        the stream is cut into sub-sequences of 2^sub_shift bits (2048 as a rule), one thread each.  Every thread
 //        decodes from the guess "a DC code of block 0 starts at my first bit"; Huffman streams
 //        self-synchronise, so a wrong guess falls into step with the true parse after a few symbols.
 //        The kernels find, for every sub-sequence, the state in which the TRUE parse enters it, and
@@ -521,7 +521,8 @@ __global__ __launch_bounds__(WR_THREADS) void k_huff_write(const HuffArgs a)
 	const JhDecFrame fr = w.frames[f];
 	const JhDecState fs = w.state[f];
 	const uint32_t total_bits = fs.cs_len * 8u;
-	const uint32_t nsub = (total_bits + JH_SUBSEQ_BITS - 1) / JH_SUBSEQ_BITS;
+	const uint32_t sub_shift = w.sub_shift;
+	const uint32_t nsub = (total_bits + (1u << sub_shift) - 1u) >> sub_shift;
 	const uint32_t t0 = blockIdx.x * (uint32_t)WR_THREADS;
 	if (t0 >= nsub) {
 		return;
@@ -563,12 +564,12 @@ __global__ __launch_bounds__(WR_THREADS) void k_huff_write(const HuffArgs a)
 			DCS_AT(dcs, k, WR_THREADS) = e.dc[k];
 		}
 		// cannot fail for records produced by decode_span
-		act = c < B && z <= 63 && seg < nseg && pos >= t * JH_SUBSEQ_BITS && pos < total_bits;
+		act = c < B && z <= 63 && seg < nseg && pos >= (t << sub_shift) && pos < total_bits;
 		if (act) {
 			seg_end = min(seg_start[seg + 1] * 8u, total_bits);
 		}
 	}
-	const uint32_t stop = (t + 1) * JH_SUBSEQ_BITS;
+	const uint32_t stop = ((t + 1) << sub_shift);
 	// the thread's flags live in ONE vector register: kept as wave masks they cost a dozen scalar instructions per
 	// symbol to merge at the ends of the divergent regions, and the scalar unit is shared by the CU's four SIMDs
 	enum { F_ACT = 1, F_OWN = 2, F_PRIMED = 4 };
@@ -849,6 +850,7 @@ __global__ __launch_bounds__(64) void k_huff_fixup(const HuffArgs a)
 	const JhDecFrame *fr = w.frames + f;
 	const uint32_t nseg = min(fs.nseg, fr->seg_cap - 1);
 	const uint32_t total_bits = fs.cs_len * 8u;
+	const uint32_t sub_shift = w.sub_shift;
 	const uint32_t *seg_start = w.seg_start + fr->seg_off;
 	const unsigned long long *drop = w.drop + fr->seg_off;
 	const unsigned char *luts = reinterpret_cast<const unsigned char *>(w.luts + fr->lut_off);

@@ -1,6 +1,6 @@
 // jpeg_amd/csrc/huffsync.hip -- finding the true parse of a Huffman stream in parallel.
 //
-// The unstuffed stream of a frame is cut into sub-sequences of JH_SUBSEQ_BITS bits.  "Chain t" is
+// The unstuffed stream of a frame is cut into sub-sequences of 2^sub_shift bits (2048 as a rule).  "Chain t" is
 // the decoder started at the first bit of sub-sequence t with the guess (DC code of block 0 next).
 // Chain 0 is the true parse.  Huffman streams self-synchronise, so chain t soon coincides with the
 // true parse -- but a JPEG decoder's state is (bit position, block-in-MCU, zig-zag index) and the
@@ -268,10 +268,11 @@ __device__ __forceinline__ void store_agg(JhWgAgg *dst, const Agg &t, uint32_t e
 // guess takes over (restart link) -- and cheap to say: left alone, such a chain idles through its sixteen steps
 // towards that segment, links to nothing, and a workgroup range whose path starts with it has to be walked again
 // (with optimised tables, where many codes do not exist, one chain in a hundred is of this kind).
-__device__ __forceinline__ bool key_garbage(unsigned long long key, uint32_t total_bits, uint32_t next_sub, uint32_t nsub)
+__device__ __forceinline__ bool key_garbage(unsigned long long key, uint32_t total_bits, uint32_t next_sub, uint32_t nsub,
+                                            uint32_t sub_shift)
 {
 	const uint32_t pos = (uint32_t)(key & 0xffffffffu);    // chain_key() and JhSubInfo.state alike
-	return next_sub < nsub && (pos >= total_bits || pos >= (next_sub + 1u) * JH_SUBSEQ_BITS);
+	return next_sub < nsub && (pos >= total_bits || pos >= ((next_sub + 1u) << sub_shift));
 }
 
 template <bool SEGMENTED>
@@ -287,7 +288,8 @@ __global__ __launch_bounds__(256) void k_huff_chains(const HuffArgs a)
 	const JhDecFrame fr = w.frames[f];
 	const JhDecState fs = w.state[f];
 	const uint32_t total_bits = fs.cs_len * 8u;
-	const uint32_t nsub = (total_bits + JH_SUBSEQ_BITS - 1) / JH_SUBSEQ_BITS;
+	const uint32_t sub_shift = w.sub_shift;
+	const uint32_t nsub = (total_bits + (1u << sub_shift) - 1u) >> sub_shift;
 	if (blockIdx.x * 256u >= nsub) {
 		return;
 	}
@@ -306,21 +308,21 @@ __global__ __launch_bounds__(256) void k_huff_chains(const HuffArgs a)
 
 	// step 0: the chain's own sub-sequence, from the guess
 	DecState st;
-	state_from(st, (unsigned long long)t * JH_SUBSEQ_BITS, 0);
+	state_from(st, (unsigned long long)t << sub_shift, 0);
 	st.seg = nseg > 1 ? find_segment(seg_start, nseg, st.pos >> 3) : 0u;
-	decode_span<SEGMENTED>(st, (t + 1) * JH_SUBSEQ_BITS, S, total_bits, seg_start, nseg, luts, tb, a.g.B, mydcs, 256, nullptr, 0, 0);
+	decode_span<SEGMENTED>(st, ((t + 1) << sub_shift), S, total_bits, seg_start, nseg, luts, tb, a.g.B, mydcs, 256, nullptr, 0, 0);
 	store_info(&rec[0], st);
 	// the exit states once more, packed: what k_huff_links and k_huff_survivors compare (8 bytes instead of a line)
 	unsigned long long *key01 = w.key01 + (size_t)(fr.sub_off + t) * 2;
 	key01[0] = chain_key(pack_state(st), st.seg);
-	if (st.pos >= total_bits || st.pos >= (t + 2) * JH_SUBSEQ_BITS || t + 1 >= nsub) {
+	if (st.pos >= total_bits || st.pos >= ((t + 2) << sub_shift) || t + 1 >= nsub) {
 		return;                            // garbage (key_garbage: k_huff_links restarts with the next chain's guess), or the last one
 	}
 	// step 1: the next sub-sequence from where step 0 ended (sums counted anew)
 	const unsigned long long ps = pack_state(st);
 	const uint32_t sg = st.seg;
 	state_from(st, ps, sg);
-	decode_span<SEGMENTED>(st, (t + 2) * JH_SUBSEQ_BITS, S, total_bits, seg_start, nseg, luts, tb, a.g.B, mydcs, 256, nullptr, 0, 0);
+	decode_span<SEGMENTED>(st, ((t + 2) << sub_shift), S, total_bits, seg_start, nseg, luts, tb, a.g.B, mydcs, 256, nullptr, 0, 0);
 	store_info(&rec[1], st);
 	key01[1] = chain_key(pack_state(st), st.seg);
 }
@@ -332,7 +334,8 @@ __global__ __launch_bounds__(256) void k_huff_links(const HuffArgs a)
 	const JhDecFrame fr = w.frames[f];
 	const JhDecState fs = w.state[f];
 	const uint32_t total_bits = fs.cs_len * 8u;
-	const uint32_t nsub = (total_bits + JH_SUBSEQ_BITS - 1) / JH_SUBSEQ_BITS;
+	const uint32_t sub_shift = w.sub_shift;
+	const uint32_t nsub = (total_bits + (1u << sub_shift) - 1u) >> sub_shift;
 	const uint32_t t = blockIdx.x * 256u + threadIdx.x;
 	if (blockIdx.x * 256u >= nsub) {
 		return;
@@ -342,16 +345,16 @@ __global__ __launch_bounds__(256) void k_huff_links(const HuffArgs a)
 		const unsigned long long *key01 = w.key01 + (size_t)(fr.sub_off + t) * 2;
 		const unsigned long long k0 = key01[0];
 		uint32_t meta;                     // steps walked | link distance << 8 | restart link
-		if (key_garbage(k0, total_bits, t + 1, nsub)) {
+		if (key_garbage(k0, total_bits, t + 1, nsub, sub_shift)) {
 			meta = 0u | (1u << 8) | META_RESTART;
 		} else if (t + 1 >= nsub) {
 			meta = 0u;
 		} else {
 			const unsigned long long k1 = key01[1];
 			const unsigned long long n0 = key01[2];            // the younger neighbour after its step 0
-			if (key_garbage(k1, total_bits, t + 2, nsub)) {
+			if (key_garbage(k1, total_bits, t + 2, nsub, sub_shift)) {
 				meta = 1u | (2u << 8) | META_RESTART;
-			} else if (!key_garbage(n0, total_bits, t + 2, nsub) && k1 == n0) {
+			} else if (!key_garbage(n0, total_bits, t + 2, nsub, sub_shift) && k1 == n0) {
 				meta = 1u | (1u << 8);                     // same state as the younger chain: identical from here on
 			} else {
 				meta = 1u;
@@ -391,7 +394,8 @@ __global__ __launch_bounds__(256) void k_huff_survivors(const HuffArgs a)
 		return;
 	}
 	const uint32_t total_bits = fs.cs_len * 8u;
-	const uint32_t nsub = (total_bits + JH_SUBSEQ_BITS - 1) / JH_SUBSEQ_BITS;
+	const uint32_t sub_shift = w.sub_shift;
+	const uint32_t nsub = (total_bits + (1u << sub_shift) - 1u) >> sub_shift;
 	load_tables(w, fr, luts, &tb, a.g, 256 * 4);
 	const int tid = threadIdx.x;
 	if (blockIdx.x * 256u + tid >= nsurv) {
@@ -412,10 +416,10 @@ __global__ __launch_bounds__(256) void k_huff_survivors(const HuffArgs a)
 		const uint32_t jl = i + d;         // < nsub
 		DecState st;
 		state_from(st, ps, sg);
-		decode_span<SEGMENTED>(st, (jl + 1) * JH_SUBSEQ_BITS, S, total_bits, seg_start, nseg, luts, tb, a.g.B, mydcs, 256, nullptr, 0, 0);
+		decode_span<SEGMENTED>(st, ((jl + 1) << sub_shift), S, total_bits, seg_start, nseg, luts, tb, a.g.B, mydcs, 256, nullptr, 0, 0);
 		store_info(&rec[d], st);
 		meta = d;
-		if ((st.pos >= total_bits || st.pos >= (jl + 2u) * JH_SUBSEQ_BITS) && jl + 1 < nsub) {
+		if ((st.pos >= total_bits || st.pos >= ((jl + 2u) << sub_shift)) && jl + 1 < nsub) {
 			meta |= ((d + 1u) << 8) | META_RESTART;        // garbage (key_garbage): restart with the next chain's guess
 			break;
 		}
@@ -428,13 +432,13 @@ __global__ __launch_bounds__(256) void k_huff_survivors(const HuffArgs a)
 		const unsigned long long *kj = w.key01 + (size_t)(fr.sub_off + jl) * 2;
 		const unsigned long long o0 = kj[0], p0 = kj[-2];
 		uint32_t hit = 0;
-		if (!key_garbage(p0, total_bits, jl, nsub)) {
+		if (!key_garbage(p0, total_bits, jl, nsub, sub_shift)) {
 			const unsigned long long p1 = kj[-1];
-			if (!key_garbage(p1, total_bits, jl + 1, nsub) && p1 == key) {
+			if (!key_garbage(p1, total_bits, jl + 1, nsub, sub_shift) && p1 == key) {
 				hit = d - 1u;
 			}
 		}
-		if (!key_garbage(o0, total_bits, jl + 1, nsub) && o0 == key) {
+		if (!key_garbage(o0, total_bits, jl + 1, nsub, sub_shift) && o0 == key) {
 			hit = d;
 		}
 		if (hit) {
@@ -460,7 +464,8 @@ __global__ __launch_bounds__(256) void k_huff_emit(const HuffArgs a)
 	const JhDecFrame fr = w.frames[f];
 	const JhDecState fs = w.state[f];
 	const uint32_t total_bits = fs.cs_len * 8u;
-	const uint32_t nsub = (total_bits + JH_SUBSEQ_BITS - 1) / JH_SUBSEQ_BITS;
+	const uint32_t sub_shift = w.sub_shift;
+	const uint32_t nsub = (total_bits + (1u << sub_shift) - 1u) >> sub_shift;
 	const uint32_t b = blockIdx.x;
 	if (nsub == 0 || b >= jh_num_chain_wgs(nsub)) {
 		return;
@@ -555,7 +560,7 @@ struct WalkCtx {
 	const uint32_t *seg_start;
 	const JhSubInfo *rec;                 // of the frame's chain 0
 	const uint32_t *meta;
-	uint32_t total_bits, nseg, nsub;
+	uint32_t total_bits, nseg, nsub, sub_shift;
 	int B;
 };
 
@@ -593,7 +598,7 @@ __device__ __forceinline__ JhSubInfo walk_step(const WalkCtx &c, unsigned long l
 			const uint32_t steps = c.meta[ch] & 0xffu;
 			if ((uint32_t)lane <= steps) {
 				if (lane == 0) {
-					const uint32_t p0 = q * JH_SUBSEQ_BITS;
+					const uint32_t p0 = (q << c.sub_shift);
 					const uint32_t s0 = c.nseg > 1 ? find_segment(c.seg_start, c.nseg, p0 >> 3) : 0u;
 					hit = chain_key((unsigned long long)p0, s0) == keyT;
 				} else {
@@ -623,7 +628,7 @@ __device__ __forceinline__ JhSubInfo walk_step(const WalkCtx &c, unsigned long l
 		if (st.c >= c.B || st.z > 63 || st.seg >= c.nseg) {
 			st.pos = c.total_bits;             // cannot happen for states produced by decode_span
 		}
-		decode_span<true>(st, (q + 1) * JH_SUBSEQ_BITS, RegStream{c.cs}, c.total_bits, c.seg_start, c.nseg, luts, tb, c.B, dcs, 64,
+		decode_span<true>(st, ((q + 1) << c.sub_shift), RegStream{c.cs}, c.total_bits, c.seg_start, c.nseg, luts, tb, c.B, dcs, 64,
 		                   nullptr, 0, 0);
 		store_info(bcast, st);
 		*selfdec += 1;
@@ -656,7 +661,8 @@ __global__ __launch_bounds__(64) void k_huff_walk(const HuffArgs a)
 	const JhDecFrame fr = w.frames[f];
 	const JhDecState fs = w.state[f];
 	const uint32_t total_bits = fs.cs_len * 8u;
-	const uint32_t nsub = (total_bits + JH_SUBSEQ_BITS - 1) / JH_SUBSEQ_BITS;
+	const uint32_t sub_shift = w.sub_shift;
+	const uint32_t nsub = (total_bits + (1u << sub_shift) - 1u) >> sub_shift;
 	if (nsub == 0 || b >= jh_num_chain_wgs(nsub) || (fs.status & JH_ST_SERIAL)) {
 		return;
 	}
@@ -697,6 +703,7 @@ __global__ __launch_bounds__(64) void k_huff_walk(const HuffArgs a)
 	c.seg_start = w.seg_start + fr.seg_off;
 	c.rec = w.rec + (size_t)fr.sub_off * (KMAX + 1);
 	c.meta = w.meta + fr.sub_off;
+	c.sub_shift = w.sub_shift;
 	c.total_bits = total_bits;
 	c.nseg = min(fs.nseg, fr.seg_cap - 1);
 	c.nsub = nsub;
@@ -788,6 +795,7 @@ __device__ void serial_walk(const HuffArgs &a, const JhDecFrame &fr, JhDecState 
 {
 	const JhDecodeWork &w = a.w;
 	const uint32_t total_bits = fs.cs_len * 8u;
+	const uint32_t sub_shift = w.sub_shift;
 	const uint8_t *cs = w.cs + fr.cs_off;
 	const uint32_t *seg_start = w.seg_start + fr.seg_off;
 	const uint32_t nseg = min(fs.nseg, fr.seg_cap - 1);
@@ -833,7 +841,7 @@ __device__ void serial_walk(const HuffArgs &a, const JhDecFrame &fr, JhDecState 
 						continue;
 					}
 					if (c == jn) {
-						const uint32_t p0 = jn * JH_SUBSEQ_BITS;
+						const uint32_t p0 = (jn << sub_shift);
 						const uint32_t s0 = nseg > 1 ? find_segment(seg_start, nseg, p0 >> 3) : 0u;
 						if (chain_key((unsigned long long)p0, s0) == keyT) {
 							r = c;
@@ -860,7 +868,7 @@ __device__ void serial_walk(const HuffArgs &a, const JhDecFrame &fr, JhDecState 
 				if (st.c >= a.g.B || st.z > 63 || st.seg >= nseg) {
 					st.pos = total_bits;       // cannot happen for states produced by decode_span
 				}
-				decode_span<true>(st, (jn + 1) * JH_SUBSEQ_BITS, RegStream{cs}, total_bits, seg_start, nseg, luts, tb, a.g.B, dcs, 64, nullptr, 0, 0);
+				decode_span<true>(st, ((jn + 1) << sub_shift), RegStream{cs}, total_bits, seg_start, nseg, luts, tb, a.g.B, dcs, 64, nullptr, 0, 0);
 				store_info(&R, st);
 			}
 		}
@@ -896,7 +904,8 @@ __global__ __launch_bounds__(64) void k_huff_finish(const HuffArgs a)
 	const JhDecFrame fr = w.frames[f];
 	JhDecState &fs = w.state[f];
 	const uint32_t total_bits = fs.cs_len * 8u;
-	const uint32_t nsub = (total_bits + JH_SUBSEQ_BITS - 1) / JH_SUBSEQ_BITS;
+	const uint32_t sub_shift = w.sub_shift;
+	const uint32_t nsub = (total_bits + (1u << sub_shift) - 1u) >> sub_shift;
 	if (nsub == 0) {
 		return;
 	}
