@@ -1144,8 +1144,8 @@ extern "C" int jpeg_hip_decoder_sync(jpeg_hip_decoder *dec, int *frame_status)
 				// that marker (decoder.c:487-657): TEM, APPn, COM, DAC and table segments pass, whatever
 				// lies between markers is skipped (io.c:196-210), EOI ends the image with what was decoded.
 				// The same walk here, on the host copy of the file (restart intervals behind such a marker have
-				// been spliced in above).  Another SOS behind it is not on the GPU path, and new quantisation
-				// tables would change the image already made.
+				// been spliced in above).  Another SOS behind it sends the batch through prepare once more (below);
+				// new quantisation tables would change the image already made and are refused.
 				st = RET_FAILURE_FILE_UNSUPPORTED;
 				JhHeader h0, h1;
 				const uint8_t *file = dec->file_ptr[f];
