@@ -1137,6 +1137,8 @@ extern "C" int jpeg_hip_decoder_sync(jpeg_hip_decoder *dec, int *frame_status)
 			dec->ecs_len[f] += ds.term_pos - fr.raw_begin + dec->spliced[f];
 			if (ds.status & JH_ST_SEG_OVERFLOW) {
 				st = RET_FAILURE_FILE_UNSUPPORTED;
+			} else if ((ds.status & JH_ST_COEF_RANGE) && dec->g.P > 12) {
+				st = RET_FAILURE_FILE_UNSUPPORTED;   // a DC coefficient beyond 16 bits (P 13 ... 16 only; jpeg_amd.h, limits)
 			} else if (ds.term_pos + 1 >= fr.raw_end) {
 				st = RET_FAILURE_FILE_IO;            // no EOI (or a lone FF as the last byte): read_marker() hits end of file (io.c:197)
 			} else if (pi + 1 == dec->pass.size() && dec->pass[pi].comp == -1 && ds.term_marker != 0xd9 && !dec->coefs_only) {
@@ -1602,7 +1604,7 @@ extern "C" int jpeg_hip_encoder_run(jpeg_hip_encoder *enc, const void *d_samples
 	// default tables: the codes are known, and the pixel kernel counts every block's AC bits while it holds the block
 	const bool acbits = !enc->prm.optimize;
 	if (jh_launch_encode_pixels(g, enc->nframes, d_samples, frame_stride, enc->d_quant, enc->d_coefs, enc->d_nzmap, enc->d_acdc,
-	                            acbits ? enc->d_codes : nullptr, s)) {
+	                            acbits ? enc->d_codes : nullptr, enc->d_state, s)) {
 		return RET_FAILURE_LOGIC_ERROR;
 	}
 	enc->timer.end(s);
@@ -2051,7 +2053,7 @@ extern "C" int jpeg_hip_encode_noalloc(int device, const jpeg_hip_params *params
 		return RET_FAILURE_LOGIC_ERROR;
 	}
 	if (jh_launch_encode_pixels(g, 1, d_samples, raw, reinterpret_cast<const JhQuant *>(base + su.off_quant),
-	                            reinterpret_cast<int16_t *>(base + off_coefs), w.nzmap, w.acdc, params->optimize ? nullptr : w.codes, s)) {
+	                            reinterpret_cast<int16_t *>(base + off_coefs), w.nzmap, w.acdc, params->optimize ? nullptr : w.codes, w.state, s)) {
 		return RET_FAILURE_LOGIC_ERROR;
 	}
 	if (params->optimize) {
@@ -2380,11 +2382,16 @@ extern "C" int jpeg_hip_encode_pixels(int device, const jpeg_hip_frame_desc *fra
 		const JhGeom &g = enc->g;
 		const size_t body = (size_t)g.X * g.Y * g.Nf * g.sample_bytes;
 		void *d_in = so.buffer(0, body ? body : 1);
-		if (!d_in || hipMemcpy(d_in, samples, body, hipMemcpyHostToDevice) != hipSuccess) {
+		JhEncState st0;
+		memset(&st0, 0, sizeof st0);
+		if (!d_in || hipMemcpy(d_in, samples, body, hipMemcpyHostToDevice) != hipSuccess ||
+		    hipMemset(enc->d_state, 0, sizeof(JhEncState)) != hipSuccess) {
 			err = RET_FAILURE_MEMORY_ALLOCATION;
-		} else if (jh_launch_encode_pixels(g, 1, d_in, body, enc->d_quant, enc->d_coefs, nullptr, nullptr, nullptr, nullptr) ||
-		           hipStreamSynchronize(nullptr) != hipSuccess) {
+		} else if (jh_launch_encode_pixels(g, 1, d_in, body, enc->d_quant, enc->d_coefs, nullptr, nullptr, nullptr, enc->d_state, nullptr) ||
+		           hipMemcpy(&st0, enc->d_state, sizeof st0, hipMemcpyDeviceToHost) != hipSuccess) {
 			err = RET_FAILURE_LOGIC_ERROR;
+		} else if (st0.status & JH_EST_NO_CODE) {
+			err = RET_FAILURE_FILE_UNSUPPORTED;            // P > 12: a coefficient beyond 16 bits (see jpeg_amd.h)
 		}
 		enc->ran = !err;
 		for (int k = 0; k < g.ncomp && !err; ++k) {
@@ -2710,9 +2717,6 @@ extern "C" int jpeg_hip_process_stream(FILE *i_stream, FILE *o_stream, const jpe
 	const size_t body = (size_t)X * Y * comps * ss;
 	if (data.size() - pos < body) {
 		return RET_FAILURE_FILE_IO;                        // frame.c:296-299
-	}
-	if (P > 12) {
-		return RET_FAILURE_FILE_UNSUPPORTED;               // int16 coefficient storage: P <= 12
 	}
 	jpeg_hip_encoder *enc = nullptr;
 	err = jpeg_hip_encoder_create(&enc, 0);

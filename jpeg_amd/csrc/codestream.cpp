@@ -205,7 +205,7 @@ int jh_build_enccodes(const JhHuffSpec *s, JhHuffEnc *e)
 
 int jh_finish_geometry(JhGeom *g)
 {
-	if (g->ncomp < 1 || g->ncomp > JH_MAX_COMP || g->X <= 0 || g->Y <= 0 || g->P < 2 || g->P > 12) {
+	if (g->ncomp < 1 || g->ncomp > JH_MAX_COMP || g->X <= 0 || g->Y <= 0 || g->P < 2 || g->P > 16) {
 		return RET_FAILURE_FILE_UNSUPPORTED;
 	}
 	if (g->ncomp == 1) {

@@ -507,7 +507,9 @@ __device__ __forceinline__ void flush_blocks(bool fin, int fblk, int4 *bufs, int
 // the careful symbol near a segment's end, undecodable data -- sits behind tests the whole wave takes together,
 // the symbol itself is straight-line code, and the DC predictors are registers (a returning LDS atomic per
 // symbol made every iteration wait for the LDS once more).
-template <bool REMAP>
+// WIDE: sample precision 13 ... 16, where the DC predictions of a valid stream can add up past the 16 bits the
+// coefficients are stored in: such a frame is reported (JH_ST_COEF_RANGE), not stored wrapped.
+template <bool REMAP, bool WIDE>
 __global__ __launch_bounds__(WR_THREADS) void k_huff_write(const HuffArgs a)
 {
 	extern __shared__ __align__(16) unsigned char smem[];
@@ -579,6 +581,7 @@ __global__ __launch_bounds__(WR_THREADS) void k_huff_write(const HuffArgs a)
 	uint4 ent_n = make_uint4(0, 0, 0, 0);
 	uint32_t wi = 0, w0 = 0, w1 = 0, w2 = 0, win = 0, tac = 0, tab = 0, comp = 0;
 	int lastold = 0;                                 // DC predictor that went into the block in progress
+	int wide = 0;
 	RegStream::Cursor cur;
 	cur.b = cur.c = cur.d = 0;
 	cur.nq = 4;
@@ -636,6 +639,9 @@ __global__ __launch_bounds__(WR_THREADS) void k_huff_write(const HuffArgs a)
 			const int old = atomicAdd(reinterpret_cast<int *>(reinterpret_cast<char *>(dcs) + comp), isdc ? val : 0);
 			val += isdc ? old : 0;
 			lastold = isdc ? old : lastold;
+			if (WIDE) {
+				wide |= isdc ? (val + 32768) : 0;                   // bit 16 and up, or negative: not an int16
+			}
 			// coefficient k of the block in progress; EOB and ZRL carry a zero, a run past the end (k > 63) stores one
 			mybuf[(min(k, 63) + rot) & 63] = (int16_t)(k < 64 ? val : 0);
 			z = done ? 0 : k + 1;
@@ -721,6 +727,9 @@ __global__ __launch_bounds__(WR_THREADS) void k_huff_write(const HuffArgs a)
 					if (isdc) {
 						lastold = atomicAdd(dcs + kc * WR_THREADS, val);
 						val += lastold;
+						if (WIDE) {
+							wide |= val + 32768;
+						}
 					}
 					const int k = z + run;
 					const bool done = k >= 63;
@@ -747,6 +756,9 @@ __global__ __launch_bounds__(WR_THREADS) void k_huff_write(const HuffArgs a)
 	// The blocks of that unfinished MCU stay (decoder.c:347-355): say so before k_coef_tail_clear asks.
 	if ((fl & F_ACT) && z == 0 && c != 0 && pos >= total_bits) {
 		atomicMax(&w.state[f].ntail, (uint32_t)max(blk, 0));
+	}
+	if (WIDE && ((unsigned)wide >> 16) != 0) {
+		atomicOr(&w.state[f].status, (uint32_t)JH_ST_COEF_RANGE);
 	}
 }
 
@@ -831,6 +843,9 @@ __device__ int fixup_segment(const HuffArgs &a, const JhDecFrame *fr, int16_t *f
 		if (dst) {
 			dst[0] = (int16_t)dcv;
 		}
+		if (dcv < -32768 || dcv > 32767) {
+			atomicOr(&a.w.state[blockIdx.x].status, (uint32_t)JH_ST_COEF_RANGE);   // P > 12 only (see k_huff_write)
+		}
 #pragma unroll
 		for (int q = 0; q < JH_MAX_COMP; ++q) {
 			pred[q] = q == comp ? dcv : pred[q];
@@ -850,7 +865,6 @@ __global__ __launch_bounds__(64) void k_huff_fixup(const HuffArgs a)
 	const JhDecFrame *fr = w.frames + f;
 	const uint32_t nseg = min(fs.nseg, fr->seg_cap - 1);
 	const uint32_t total_bits = fs.cs_len * 8u;
-	const uint32_t sub_shift = w.sub_shift;
 	const uint32_t *seg_start = w.seg_start + fr->seg_off;
 	const unsigned long long *drop = w.drop + fr->seg_off;
 	const unsigned char *luts = reinterpret_cast<const unsigned char *>(w.luts + fr->lut_off);
@@ -898,17 +912,15 @@ int jh_launch_huff_decode(const JhDecodeWork &w, const JhGeom &g, hipStream_t s,
 	}
 	// one launch configuration for the batch: LDS for the largest table set of any frame
 	const size_t lds = sizeof(JhHuffLut) * (size_t)w.max_luts + (size_t)WR_THREADS * 128;
-	const void *wr = w.rm.mode ? reinterpret_cast<const void *>(k_huff_write<true>) : reinterpret_cast<const void *>(k_huff_write<false>);
-	if (hipFuncSetAttribute(wr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+	const bool wide = g.P > 12;
+	void (*wr)(const HuffArgs) = w.rm.mode ? (wide ? k_huff_write<true, true> : k_huff_write<true, false>)
+	                                       : (wide ? k_huff_write<false, true> : k_huff_write<false, false>);
+	if (hipFuncSetAttribute(reinterpret_cast<const void *>(wr), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
 		return -1;
 	}
 	dim3 gsub((w.max_subs + WR_THREADS - 1) / WR_THREADS, w.nframes);
 	JH_T_BEGIN(th, "k_huff_write", s);
-	if (w.rm.mode) {
-		hipLaunchKernelGGL(k_huff_write<true>, gsub, dim3(WR_THREADS), lds, s, a);
-	} else {
-		hipLaunchKernelGGL(k_huff_write<false>, gsub, dim3(WR_THREADS), lds, s, a);
-	}
+	hipLaunchKernelGGL(wr, gsub, dim3(WR_THREADS), lds, s, a);
 	JH_T_END(th, s);
 	JH_T_BEGIN(th, "k_huff_fixup", s);
 	hipLaunchKernelGGL(k_huff_fixup, dim3(w.nframes), dim3(64), 0, s, a);

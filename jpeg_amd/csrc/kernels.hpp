@@ -35,6 +35,7 @@ struct JhDecFrame {               // written by the host in prepare()
 enum {                            // JhDecState.status bits
 	JH_ST_SEG_OVERFLOW = 1,       // more restart segments than reserved
 	JH_ST_SERIAL = 2,             // the parallel synchronisation gave up on this frame: serial walk used
+	JH_ST_COEF_RANGE = 4,         // P > 12: a DC coefficient left the 16 bits coefficients are stored in
 };
 
 struct JhDecState {               // written by the device
@@ -115,11 +116,12 @@ int jh_launch_decode_pixels(const JhGeom &g, int nframes, const int16_t *coefs, 
 // read by k_enc_dcbits (DC symbol + sums) and by k_enc_pack instead of a second look at the coefficients.
 #define JH_ACBITS_NOCODE 0xffffu
 
+// state: NULL, or the frames' states: for P > 12 a coefficient beyond 16 bits sets JH_EST_NO_CODE there.
 // codes: NULL, or the frames' codes ([frame][4]): the kernel then also fills nzmap[] / acdc[] ([frame][nblk]) with
 // the AC code sizes of codes[frame * 4 + 2 + Ta]
 int jh_launch_encode_pixels(const JhGeom &g, int nframes, const void *in, size_t frame_stride,
                             const JhQuant *quant_raster, int16_t *coefs, unsigned long long *nzmap, uint32_t *acdc,
-                            const JhHuffEnc *codes, hipStream_t stream);
+                            const JhHuffEnc *codes, struct JhEncState *state, hipStream_t stream);
 
 int jh_launch_selftest_divide(unsigned long long *d_out, int per, unsigned seed, hipStream_t stream);
 

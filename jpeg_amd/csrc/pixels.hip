@@ -511,6 +511,7 @@ struct EncPixArgs {
 	int16_t *coefs;            // [frame][nblk][64] zig-zag
 	unsigned long long *nzmap; // [frame][nblk] (with codes)
 	uint32_t *acdc;            // [frame][nblk] (with codes)
+	JhEncState *state;         // [frame], or NULL: a coefficient that does not fit 16 bits is reported there
 	const JhHuffEnc *codes;    // [frame][4] the codes in force for the frame, or NULL
 	TileLayout L;
 	JhGeom g;
@@ -739,6 +740,24 @@ __global__ __launch_bounds__(256) void k_encode_pixels(const EncPixArgs a)
 				}
 			}
 		}
+		// Coefficients are stored in 16 bits.  Up to 12 bits of sample precision nothing larger can come out of the
+		// DCT; beyond (P 13 ... 16 with small divisors) it can: category 16 and up, for which no Huffman table has
+		// a code (coeffs.c:56-74, huffman.c:252) -- the frame fails with that error.
+		if (a.state) {                                // P > 12 only
+			int wide = 0;                             // negative <=> some |coefficient| > 32767
+#pragma unroll
+			for (int it = 0; it < TILE_ROUNDS; ++it) {
+				if (tid + it * 256 < ntask) {
+#pragma unroll
+					for (int u = 0; u < 8; ++u) {
+						wide |= (iq[it][u] + 32767) | (32767 - iq[it][u]);
+					}
+				}
+			}
+			if (wide < 0) {
+				atomicOr(&a.state[f].status, (uint32_t)JH_EST_NO_CODE);
+			}
+		}
 		__syncthreads();                              // every column has been read: the blocks' int16 lines go over the planes
 #pragma unroll
 		for (int it = 0; it < TILE_ROUNDS; ++it) {
@@ -842,7 +861,7 @@ __global__ __launch_bounds__(256) void k_encode_pixels(const EncPixArgs a)
 
 int jh_launch_encode_pixels(const JhGeom &g, int nframes, const void *in, size_t frame_stride,
                             const JhQuant *quant_raster, int16_t *coefs, unsigned long long *nzmap, uint32_t *acdc,
-                            const JhHuffEnc *codes, hipStream_t stream)
+                            const JhHuffEnc *codes, JhEncState *state, hipStream_t stream)
 {
 	EncPixArgs a;
 	a.in = (const uint8_t *)in;
@@ -852,6 +871,7 @@ int jh_launch_encode_pixels(const JhGeom &g, int nframes, const void *in, size_t
 	a.nzmap = nzmap;
 	a.acdc = acdc;
 	a.codes = nzmap && acdc ? codes : nullptr;
+	a.state = g.P > 12 ? state : nullptr;
 	make_layout(g, &a.L);
 	a.g = g;
 	dim3 grid((g.m_x + a.L.G - 1) / a.L.G, g.m_y, nframes);

@@ -57,3 +57,16 @@ def zero_run_past_block_end(oracle, value_cat=0):
     dc(-2)                             # block 2: DC 5 - 2 = 3, EOB
     ac(0, 0)
     return head + w.bytes() + b"\xff\xd9", {1: {0: 5, 1: 3}, 2: {0: 3}}
+
+
+def deep_image(P, nc, X=160, Y=96, seed=1):
+    """A low-contrast image around mid grey with P bits per sample (13 ... 16): what the reference encoder takes at
+    such precisions, where its assert on |DC| <= 2047 (encoder.c:447, :501) also holds for the first block."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:Y, 0:X]
+    a = (1 << (P - 1)) + ((np.sin(xx / 9.0) + np.cos(yy / 7.0)) * (1 << (P - 6))).astype(np.int64)
+    a = a + rng.integers(-(1 << (P - 9)), 1 << (P - 9), size=(Y, X))
+    a = np.clip(a, 0, (1 << P) - 1).astype(np.uint16)
+    if nc == 3:
+        a = np.stack([a, np.roll(a, 5, 1), np.roll(a, 9, 0)], -1)
+    return a

@@ -105,10 +105,12 @@ def test_error_codes_of_the_drop_ins(hip, oracle, tmp_path):
     _, jpg, _ = oracle.encode(img, P=8, H=2, V=2, q=75, optimize=1)
     bad.write_bytes(jpg[:-2])                                                              # no EOI
     assert L.jpeg_hip_process_jpeg_file(str(bad).encode(), str(tmp_path / "o.ppm").encode()) == 0x1000
-    # PPM problems: body too short (frame.c:296-299), 16-bit samples beyond P = 12
+    # PPM problems: body too short (frame.c:296-299), a maxval beyond 16 bits (frame.c:499-503), 16-bit samples far
+    # from mid grey (the reference's assert on the DC coefficient, encoder.c:447: a status here)
     prm = hip.Params(2, 2, 75, 1)
     for body, want in ((b"P6\n64 48\n255\n" + bytes(100), 0x1000),
-                       (b"P5\n8 8\n65535\n" + bytes(128), 0x1001),
+                       (b"P5\n8 8\n70000\n" + bytes(128), 0x1001),
+                       (b"P5\n8 8\n65535\n" + bytes(128), 0x5001),
                        (b"P7\n8 8\n255\n" + bytes(64), 0x1001)):
         src = tmp_path / "in.pnm"
         src.write_bytes(body)

@@ -613,6 +613,43 @@ def test_pinned_frames_scattered_over_memory(hip, oracle):
         b.close()
 
 
+@pytest.mark.parametrize("P", [13, 14, 15, 16])
+def test_sample_precisions_beyond_12_bits(hip, oracle, P):
+    """frame.c:270-275: any maxval up to 65535, so P up to 16.  The reference's own assert on |DC| <= 2047
+    (encoder.c:447) leaves it low-contrast images around mid grey at such precisions; their coefficients fit the
+    16 bits this path stores (a frame whose do not is refused, not stored wrapped).  Codestream bytes, coefficients
+    and decoded samples against the oracle, both table modes, gray and 4:2:0, restart intervals."""
+    from tests.damaged import deep_image
+    for nc, H, V in ((1, 1, 1), (3, 2, 2), (3, 1, 1)):
+        img = deep_image(P, nc, seed=P + nc)
+        for q, opt, ri in ((30, 1, 0), (50, 0, 0), (50, 1, 7)):
+            err, ojpg, oinfo = oracle.encode(img, P=P, H=H, V=V, q=q, optimize=opt, restart_interval=ri)
+            assert err == 0, (P, nc, q, opt)
+            e = hip.Encoder()
+            e.configure(1, img.shape[1], img.shape[0], nc, P, H, V, q, opt, ri)
+            e.run(e.upload([img]))
+            st, ln = e.sync()
+            assert st == [0], (P, nc, q, opt)
+            _assert_coefs(e.coefficients(0), oinfo)
+            assert md5(e.jpeg(0, ln[0])) == md5(ojpg), (P, nc, q, opt, ri)
+            e.close()
+            oerr, opx, odinfo = oracle.decode(ojpg)
+            assert oerr == 0
+            d = hip.Decoder()
+            d.prepare([ojpg, ojpg])
+            out = d.run()
+            assert d.sync() == [0, 0]
+            _assert_coefs(d.coefficients(1), odinfo)
+            for px in d.to_arrays(out):
+                assert np.array_equal(px, opx), (P, nc, q, opt, ri)
+            d.close()
+    # an image the reference refuses (DC out of range): the same error here
+    bright = np.full((32, 64), (1 << P) - 1, np.uint16)
+    assert oracle.encode(bright, P=P, H=1, V=1, q=90, optimize=1)[0] == 0x5001
+    jp, st = hip.encode([bright], P=P, q=90, optimize=1)
+    assert st == [hip.JPEG_HIP_ERR_DC_RANGE]
+
+
 def test_markers_the_reference_rejects(hip, oracle):
     """APP9 / APP10 / APP15 / DNL end the reference's parse_format() with "unhandled marker"
     (decoder.c:654-656): the default is the same status; set_tolerant() skips such segments."""

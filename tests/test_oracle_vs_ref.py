@@ -237,3 +237,19 @@ def test_components_coded_more_than_once(oracle, reference):
             er, pr, ir = reference.decode(jpg)
             assert eo == er == 0
             assert _same_coefs(io, ir) and np.array_equal(po, pr)
+
+
+def test_sample_precisions_beyond_12_bits(oracle, reference):
+    """P 13 ... 16 (frame.c:270-275): the oracle against the compiled reference, both directions, on the
+    low-contrast images the reference's DC assert leaves it at such precisions (the GPU test uses the same)."""
+    from tests.damaged import deep_image
+    for P in (13, 14, 15, 16):
+        for nc, H, V in ((1, 1, 1), (3, 2, 2)):
+            img = deep_image(P, nc, seed=P + nc)
+            for q, opt in ((30, 1), (50, 0)):
+                eo, jo, io = oracle.encode(img, P=P, H=H, V=V, q=q, optimize=opt)
+                er, jr, ir = reference.encode(img, P=P, H=H, V=V, q=q, optimize=opt)
+                assert eo == er == 0 and jo == jr, (P, nc, q, opt)
+                do, po, ido = oracle.decode(jo)
+                dr, pr, idr = reference.decode(jo)
+                assert do == dr == 0 and np.array_equal(po, pr) and _same_coefs(ido, idr)
