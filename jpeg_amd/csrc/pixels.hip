@@ -121,11 +121,15 @@ __device__ __forceinline__ float quant_reciprocal(float d)
 	return __builtin_fmaf(e0, r0, r0);
 }
 
-__device__ __forceinline__ float quant_divide(float n, float d, float r1)
+// nd = -d (the table holds it negated: the fused steps want -d, and a packed FMA would spend an instruction on
+// the sign).  T: float, or f2 for two quotients at a time (v_pk_mul_f32 / v_pk_fma_f32: each half rounds like
+// the scalar instruction).
+template <typename T>
+__device__ __forceinline__ T quant_divide(T n, T nd, T r1)
 {
-	const float q0 = n * r1;
-	const float q1 = __builtin_fmaf(__builtin_fmaf(-d, q0, n), r1, q0);
-	return __builtin_fmaf(__builtin_fmaf(-d, q1, n), r1, q1);
+	const T q0 = n * r1;
+	const T q1 = __builtin_elementwise_fma(__builtin_elementwise_fma(nd, q0, n), r1, q0);
+	return __builtin_elementwise_fma(__builtin_elementwise_fma(nd, q1, n), r1, q1);
 }
 
 // ---- tile layout (host computed, shared by both kernels) -----------------------------------------
@@ -134,6 +138,7 @@ struct TileLayout {
 	unsigned b_magic16;                 // floor(2^16 / B) + 1: mcu = (block * b_magic16) >> 16 for block < 2^16 / B
 	int TW, TH;                         // tile size in frame pixels
 	unsigned qpr_magic;                 // floor(2^32 / (TW/4)) + 1
+	int q_rows, q_rest;                 // 256 quads on = q_rows rows and q_rest quads on (a workgroup's stride in stage 1 / D)
 	int base[JH_MAX_COMP], pitch[JH_MAX_COMP];          // component planes in LDS (floats)
 	int koff[JH_MAX_MCU_BLOCKS];        // block k of MCU 0: offset of its top-left sample
 	int kpitch[JH_MAX_MCU_BLOCKS];
@@ -155,6 +160,8 @@ static void make_layout(const JhGeom &g, TileLayout *t)
 	t->TW = G * 8 * g.max_H;
 	t->TH = 8 * g.max_V;
 	t->qpr_magic = (unsigned)(0x100000000ull / (unsigned)(t->TW / 4)) + 1u;
+	t->q_rows = 256 / (t->TW / 4);
+	t->q_rest = 256 % (t->TW / 4);
 	int off = 0;
 	for (int c = 0; c < g.ncomp; ++c) {
 		t->base[c] = off;
@@ -243,8 +250,9 @@ template <int SX>
 __device__ __forceinline__ void fetch4(const float *tile, const TileLayout &L, const JhGeom &g, int c,
                                        int row, int px0, float (&s)[4])
 {
-	const int cy = (row * L.sy_magic[c]) >> 16;
-	const float *p = tile + L.base[c] + cy * L.pitch[c];
+	// 24-bit multiplies (row < 32, magic <= 65537, pitch < 2^12): full rate, the 32-bit one is not
+	const unsigned cy = __umul24((unsigned)row, (unsigned)L.sy_magic[c]) >> 16;
+	const float *p = tile + L.base[c] + __umul24(cy, (unsigned)L.pitch[c]);
 	const int step = SX ? SX : g.step_x[c];
 	if (step == 1) {
 		const float4 v = *reinterpret_cast<const float4 *>(p + px0);
@@ -258,7 +266,7 @@ __device__ __forceinline__ void fetch4(const float *tile, const TileLayout &L, c
 	} else {
 #pragma unroll
 		for (int i = 0; i < 4; ++i) {
-			s[i] = p[((px0 + i) * L.sx_magic[c]) >> 16];
+			s[i] = p[__umul24((unsigned)(px0 + i), (unsigned)L.sx_magic[c]) >> 16];
 		}
 	}
 }
@@ -310,17 +318,16 @@ __global__ __launch_bounds__(256) void k_decode_pixels(const DecPixArgs a)
 
 	// ---- B: (block, row): dequantize_block (imgproc.c:17), rows first (imgproc.c:134-140) ---------
 	{
-		int zrow[8];                                  // zig-zag places of raster row `sub`
-#pragma unroll
+		const int16_t *zp[8];                         // the zig-zag places of raster row `sub` in the line of this thread's
+#pragma unroll                                        // block of round 0 (a round on: 32 lines on)
 		for (int x = 0; x < 8; ++x) {
-			zrow[x] = kt.invz[sub * 8 + x];
+			zp[x] = reinterpret_cast<const int16_t *>(tile) + (tid >> 3) * 64 + kt.invz[sub * 8 + x];
 		}
 		float rowv[TILE_ROUNDS][8];
 #pragma unroll
 		for (int it = 0; it < TILE_ROUNDS; ++it) {
 			const int t = tid + it * 256;
 			if (t < ntask) {
-				const int16_t *line = reinterpret_cast<const int16_t *>(tile) + (t >> 3) * 64;
 				const uint4 qw = *reinterpret_cast<const uint4 *>(&sq[bts[it].tq][sub * 8]);
 				const unsigned qs[4] = {qw.x, qw.y, qw.z, qw.w};
 				float in[8];
@@ -328,7 +335,7 @@ __global__ __launch_bounds__(256) void k_decode_pixels(const DecPixArgs a)
 				for (int x = 0; x < 8; ++x) {
 					const int q = (int)((x & 1) ? (qs[x >> 1] >> 16) : (qs[x >> 1] & 0xffffu));
 					// int32 product, then int -> float; |c| < 2^15 and q < 2^16: the 24-bit multiply is exact
-					in[x] = (float)__mul24((int)line[zrow[x]], q);
+					in[x] = (float)__mul24((int)zp[x][it * 32 * 64], q);
 				}
 				dct1<true>(in, rowv[it]);
 			}
@@ -338,7 +345,7 @@ __global__ __launch_bounds__(256) void k_decode_pixels(const DecPixArgs a)
 		for (int it = 0; it < TILE_ROUNDS; ++it) {
 			const int t = tid + it * 256;
 			if (t < ntask) {
-				float4 *p = reinterpret_cast<float4 *>(tile + bts[it].addr + sub * bts[it].pitch);
+				float4 *p = reinterpret_cast<float4 *>(tile + bts[it].addr + (int)__umul24((unsigned)sub, (unsigned)bts[it].pitch));
 				p[0] = make_float4(rowv[it][0], rowv[it][1], rowv[it][2], rowv[it][3]);
 				p[1] = make_float4(rowv[it][4], rowv[it][5], rowv[it][6], rowv[it][7]);
 			}
@@ -353,17 +360,19 @@ __global__ __launch_bounds__(256) void k_decode_pixels(const DecPixArgs a)
 		for (int it = 0; it < TILE_ROUNDS; ++it) {
 			const int t = tid + it * 256;
 			if (t < ntask) {
-				const int pitch = bts[it].pitch;
+				const unsigned pitch = (unsigned)bts[it].pitch;
 				float *p = tile + bts[it].addr + sub;
 				float in[8], o[8];
 #pragma unroll
 				for (int u = 0; u < 8; ++u) {
-					in[u] = p[u * pitch];
+					in[u] = p[__umul24((unsigned)u, pitch)];
 				}
 				dct1<true>(in, o);
 #pragma unroll
-				for (int y = 0; y < 8; ++y) {
-					p[y * pitch] = o[y] + shiftf;
+				for (int y = 0; y < 8; y += 2) {
+					const f2 v = f2{o[y], o[y + 1]} + f2{shiftf, shiftf};
+					p[__umul24((unsigned)y, pitch)] = v.x;
+					p[__umul24((unsigned)y + 1u, pitch)] = v.y;
 				}
 			}
 		}
@@ -379,10 +388,17 @@ __global__ __launch_bounds__(256) void k_decode_pixels(const DecPixArgs a)
 	const int denom = 1 << g.P;
 	(void)denom;
 	(void)shift;
-	uint8_t *outf = a.out + (size_t)f * a.frame_stride;
+	// The tile's first sample in the output, and offsets from there by 24-bit multiplies (rowbytes < 2^19, row < 32)
+	const unsigned pxbytes = (unsigned)(oc * g.sample_bytes), rowbytes = (unsigned)X * pxbytes;
+	uint8_t *org = a.out + (size_t)f * a.frame_stride + (size_t)(my * L.TH) * rowbytes + (size_t)(mx0 * 8 * g.max_H) * pxbytes;
 
+	// (row, quad) of this thread's first group by one division, of the next ones by stepping
+	int row_n = (int)__umulhi((unsigned)tid, L.qpr_magic), quad_n = tid - row_n * qpr;
 	for (int qd = tid; qd < L.TH * qpr; qd += 256) {
-		const int row = (int)__umulhi((unsigned)qd, L.qpr_magic), px0 = (qd - row * qpr) * 4;
+		const int row = row_n, px0 = quad_n * 4;
+		quad_n += L.q_rest;
+		row_n += L.q_rows + (quad_n >= qpr);
+		quad_n -= quad_n >= qpr ? qpr : 0;
 		const int gy = my * L.TH + row, gx0 = mx0 * 8 * g.max_H + px0;
 		if (gy >= Y || gx0 >= X) {
 			continue;
@@ -431,32 +447,43 @@ __global__ __launch_bounds__(256) void k_decode_pixels(const DecPixArgs a)
 		}
 		const int npx = min(4, X - gx0);
 		if (g.sample_bytes == 1) {
-			uint8_t *p = outf + ((size_t)gy * X + gx0) * oc;
+			uint8_t *p = org + (__umul24((unsigned)row, rowbytes) + __umul24((unsigned)px0, pxbytes));
 			if (npx == 4 && ((reinterpret_cast<uintptr_t>(p) & 3) == 0)) {
 				uint32_t *pw = reinterpret_cast<uint32_t *>(p);
 #pragma unroll
 				for (int wd = 0; wd < oc; ++wd) {
-					pw[wd] = res[4 * wd] | (res[4 * wd + 1] << 8) | (res[4 * wd + 2] << 16) | (res[4 * wd + 3] << 24);
+					// three byte permutes (v_perm_b32: selector bytes 0-3 take from the second operand, 4-7 from the
+					// first, 0x0c is zero); shifts and ors come out as five or six instructions
+					const unsigned lo = __builtin_amdgcn_perm((unsigned)res[4 * wd + 1], (unsigned)res[4 * wd], 0x0c0c0400u);
+					const unsigned hi = __builtin_amdgcn_perm((unsigned)res[4 * wd + 3], (unsigned)res[4 * wd + 2], 0x0c0c0400u);
+					pw[wd] = __builtin_amdgcn_perm(hi, lo, 0x05040100u);
 				}
 			} else {
-				for (int i = 0; i < npx * oc; ++i) {
-					p[i] = (uint8_t)res[i];
+				// (unrolled: a run-time index would keep a second copy of res[] in registers the index can select from)
+#pragma unroll
+				for (int i = 0; i < 4 * oc; ++i) {
+					if (i < npx * oc) {
+						p[i] = (uint8_t)res[i];
+					}
 				}
 			}
 		} else {
 			// big-endian 16-bit samples (htons, frame.c:386)
-			uint8_t *p = outf + ((size_t)gy * X + gx0) * oc * 2;
+			uint8_t *p = org + (__umul24((unsigned)row, rowbytes) + __umul24((unsigned)px0, pxbytes));
 			if (npx == 4 && ((reinterpret_cast<uintptr_t>(p) & 3) == 0)) {
 				uint32_t *pw = reinterpret_cast<uint32_t *>(p);
 #pragma unroll
 				for (int wd = 0; wd < 2 * oc; ++wd) {
-					const int s0 = res[2 * wd], s1 = res[2 * wd + 1];
-					pw[wd] = (s0 >> 8) | ((s0 & 0xff) << 8) | ((s1 >> 8) << 16) | ((s1 & 0xff) << 24);
+					// bytes s0.1 s0.0 s1.1 s1.0 in one permute
+					pw[wd] = __builtin_amdgcn_perm((unsigned)res[2 * wd + 1], (unsigned)res[2 * wd], 0x04050001u);
 				}
 			} else {
-				for (int i = 0; i < npx * oc; ++i) {
-					p[2 * i] = (uint8_t)(res[i] >> 8);
-					p[2 * i + 1] = (uint8_t)res[i];
+#pragma unroll
+				for (int i = 0; i < 4 * oc; ++i) {
+					if (i < npx * oc) {
+						p[2 * i] = (uint8_t)(res[i] >> 8);
+						p[2 * i + 1] = (uint8_t)res[i];
+					}
 				}
 			}
 		}
@@ -519,11 +546,16 @@ struct EncPixArgs {
 
 // 4 horizontally adjacent samples-tuples of the input body as floats: read_frame_body (frame.c:295-345)
 // incl. its padding rule (last column / last row replicated).  Fast path: whole dwords.
+// `org` is the tile's first sample (inside the frame: tiles start at MCU corners), (tx, ty) the place inside the
+// tile and (gx0, gy) = the tile's corner + (tx, ty) in the frame.  Offsets from `org` stay below 2^24 * 16
+// and are made with 24-bit multiplies (rowbytes = X * NF * sb < 2^19, ty < 16): the full-width integer
+// multiply runs at a quarter of the rate.
 template <int NF>
-__device__ __forceinline__ void load4(const uint8_t *inf, int X, int Y, int sb, int gx0, int gy, float (&s)[4][NF])
+__device__ __forceinline__ void load4(const uint8_t *org, unsigned rowbytes, int tx, int ty, int X, int Y, int sb, int gx0, int gy,
+                                      float (&s)[4][NF])
 {
 	if (gx0 + 3 < X && gy < Y) {
-		const uint8_t *p = inf + ((size_t)gy * X + gx0) * NF * sb;
+		const uint8_t *p = org + (__umul24((unsigned)ty, rowbytes) + __umul24((unsigned)tx, (unsigned)(NF * sb)));
 		if ((reinterpret_cast<uintptr_t>(p) & 3) == 0) {
 			const uint32_t *pw = reinterpret_cast<const uint32_t *>(p);
 			if (sb == 1) {
@@ -551,11 +583,11 @@ __device__ __forceinline__ void load4(const uint8_t *inf, int X, int Y, int sb, 
 			return;
 		}
 	}
-	const int sy = min(gy, Y - 1);
+	const int sy = min(gy, Y - 1) - (gy - ty);            // inside the tile again
 #pragma unroll
 	for (int i = 0; i < 4; ++i) {
-		const int sx = min(gx0 + i, X - 1);
-		const uint8_t *p = inf + ((size_t)sy * X + sx) * NF * sb;
+		const int sx = min(gx0 + i, X - 1) - (gx0 - tx);
+		const uint8_t *p = org + (__umul24((unsigned)sy, rowbytes) + __umul24((unsigned)sx, (unsigned)(NF * sb)));
 #pragma unroll
 		for (int c = 0; c < NF; ++c) {
 			s[i][c] = sb == 1 ? (float)p[c] : (float)((p[2 * c] << 8) | p[2 * c + 1]);
@@ -563,13 +595,20 @@ __device__ __forceinline__ void load4(const uint8_t *inf, int X, int Y, int sb, 
 	}
 }
 
-// bit 0: the low int16 of d is nonzero, bit 1: the high one
-__device__ __forceinline__ unsigned nz_pair16(int d)
+// bits 0 ... 7 (and rubbish above them): which of the eight int16 of v are not zero.  min(x, 1) on both halves
+// of a dword leaves the flags in bits 0 and 16; the four dwords go two bits apart, the high halves come down by
+// 15.  (Written as an instruction: the compiler turns min(x, 1) into compare + select + permute, three times
+// the work.)
+__device__ __forceinline__ unsigned nz_octet(const int4 v)
 {
-	typedef unsigned short us2 __attribute__((ext_vector_type(2)));
-	const us2 one = {1, 1};
-	const unsigned x = __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(us2, d), one));
-	return (x | (x >> 15)) & 3u;
+	const unsigned ones = 0x00010001u;
+	unsigned a, b, c, d;
+	asm("v_pk_min_u16 %0, %1, %2" : "=v"(a) : "v"(v.x), "v"(ones));
+	asm("v_pk_min_u16 %0, %1, %2" : "=v"(b) : "v"(v.y), "v"(ones));
+	asm("v_pk_min_u16 %0, %1, %2" : "=v"(c) : "v"(v.z), "v"(ones));
+	asm("v_pk_min_u16 %0, %1, %2" : "=v"(d) : "v"(v.w), "v"(ones));
+	const unsigned acc = a | (b << 2) | (c << 4) | (d << 6);
+	return acc | (acc >> 15);
 }
 
 // Stage 5 of the encode kernel (bits of every block's AC symbols) works in the part of the tile's LDS that
@@ -592,8 +631,10 @@ template <int NF, int SX, int SY>
 __global__ __launch_bounds__(256) void k_encode_pixels(const EncPixArgs a)
 {
 	extern __shared__ __align__(16) float tile[];
-	__shared__ float2 sqf[2][64];     // x: divisor, y: its refined reciprocal (see quant_divide); the encoder's frames
-	                                  // use tables 0 / 1 only (encoder.c:133-135)
+	// Per table (the encoder's frames use tables 0 / 1 only, encoder.c:133-135), raster column c and pair of rows
+	// (2p, 2p + 1): the two divisors, negated, and their refined reciprocals (see quant_divide) -- what a thread
+	// of stage 3 wants for two of its coefficients, in one 16-byte read.
+	__shared__ float4 sqf[2][8][4];
 	__shared__ KTab kt;
 	Stage5 &s5 = *reinterpret_cast<Stage5 *>(reinterpret_cast<char *>(tile) + STAGE5_OFF);
 
@@ -607,11 +648,17 @@ __global__ __launch_bounds__(256) void k_encode_pixels(const EncPixArgs a)
 	const int X = g.X, Y = g.Y;
 	const int shift = 1 << (g.P - 1);
 	const float shiftf = (float)shift;
-	const uint8_t *inf = a.in + (size_t)f * a.frame_stride;
+	const unsigned rowbytes = (unsigned)X * (unsigned)(NF * g.sample_bytes);
+	// the tile's first sample
+	const uint8_t *org = a.in + (size_t)f * a.frame_stride + (size_t)(my * L.TH) * rowbytes +
+		(size_t)(mx0 * 8 * g.max_H) * (size_t)(NF * g.sample_bytes);
 
 	for (int i = tid; i < 2 * 64; i += 256) {
 		const float d = (float)a.quant[f].q[i >> 6][i & 63];
-		sqf[i >> 6][i & 63] = make_float2(d, quant_reciprocal(d));
+		const int u = (i >> 3) & 7, c = i & 7;
+		float *e = reinterpret_cast<float *>(&sqf[i >> 6][c][u >> 1]) + (u & 1);
+		e[0] = -d;
+		e[2] = quant_reciprocal(d);
 	}
 	stage_ktab(kt, L, B, tid);
 
@@ -620,8 +667,12 @@ __global__ __launch_bounds__(256) void k_encode_pixels(const EncPixArgs a)
 		const int qpr = L.TW >> 2;
 		const int wpx = nmcu_here * 8 * g.max_H;
 		const int ngroups = (L.TH / SY) * qpr;
+		int rg_n = (int)__umulhi((unsigned)tid, L.qpr_magic), quad_n = tid - rg_n * qpr;
 		for (int qd = tid; qd < ngroups; qd += 256) {
-			const int rg = (int)__umulhi((unsigned)qd, L.qpr_magic), px0 = (qd - rg * qpr) * 4;
+			const int rg = rg_n, px0 = quad_n * 4;
+			quad_n += L.q_rest;
+			rg_n += L.q_rows + (quad_n >= qpr);
+			quad_n -= quad_n >= qpr ? qpr : 0;
 			if (px0 >= wpx) {
 				continue;
 			}
@@ -631,7 +682,7 @@ __global__ __launch_bounds__(256) void k_encode_pixels(const EncPixArgs a)
 			for (int sy = 0; sy < SY; ++sy) {
 				const int row = rg * SY + sy, gy = my * L.TH + row;
 				float s[4][NF];
-				load4<NF>(inf, X, Y, g.sample_bytes, gx0, gy, s);
+				load4<NF>(org, rowbytes, px0, row, X, Y, g.sample_bytes, gx0, gy, s);
 				float y4[4];
 #pragma unroll
 				for (int i = 0; i < 4; ++i) {
@@ -651,10 +702,10 @@ __global__ __launch_bounds__(256) void k_encode_pixels(const EncPixArgs a)
 						ch[1][sy][i] = s[i][2];
 					}
 					// luma: step 1 x 1: px = 0.f + s; px /= 1 (frame.c:114-123); then the level shift
-					// of forward_dct (imgproc.c:220-222)
-					y4[i] = (0.f + s[i][0]) - shiftf;
+					// of forward_dct (imgproc.c:220-222).  s is a sample or a luma value, never -0: 0.f + s == s
+					y4[i] = s[i][0] - shiftf;
 				}
-				*reinterpret_cast<float4 *>(tile + L.base[0] + row * L.pitch[0] + px0) =
+				*reinterpret_cast<float4 *>(tile + L.base[0] + (int)__umul24((unsigned)row, (unsigned)L.pitch[0]) + px0) =
 					make_float4(y4[0], y4[1], y4[2], y4[3]);
 			}
 			if constexpr (NF == 3) {
@@ -663,19 +714,22 @@ __global__ __launch_bounds__(256) void k_encode_pixels(const EncPixArgs a)
 					float o[4 / SX];
 #pragma unroll
 					for (int ox = 0; ox < 4 / SX; ++ox) {
-						// transform_frame_to_components (frame.c:114-123): px = 0.f; += (yy outer, xx inner); /= area
-						float px = 0.f;
+						// transform_frame_to_components (frame.c:114-123): px = 0.f; += (yy outer, xx inner); /= area.
+						// The first term is a sample or `... + shift` in binary64, never -0: 0.f + it == it
+						float px = ch[c][0][ox * SX];
 #pragma unroll
 						for (int yy = 0; yy < SY; ++yy) {
 #pragma unroll
 							for (int xx = 0; xx < SX; ++xx) {
-								px += ch[c][yy][ox * SX + xx];
+								if (yy + xx) {
+									px += ch[c][yy][ox * SX + xx];
+								}
 							}
 						}
 						px /= (float)(SY * SX);
 						o[ox] = px - shiftf;
 					}
-					float *dst = tile + L.base[c + 1] + rg * L.pitch[c + 1] + px0 / SX;
+					float *dst = tile + L.base[c + 1] + (int)__umul24((unsigned)rg, (unsigned)L.pitch[c + 1]) + px0 / SX;
 					if constexpr (SX == 1) {
 						*reinterpret_cast<float4 *>(dst) = make_float4(o[0], o[1], o[2], o[3]);
 					} else {
@@ -700,7 +754,7 @@ __global__ __launch_bounds__(256) void k_encode_pixels(const EncPixArgs a)
 	for (int it = 0; it < TILE_ROUNDS; ++it) {
 		const int t = tid + it * 256;
 		if (t < ntask) {
-			float4 *p = reinterpret_cast<float4 *>(tile + bts[it].addr + sub * bts[it].pitch);
+			float4 *p = reinterpret_cast<float4 *>(tile + bts[it].addr + (int)__umul24((unsigned)sub, (unsigned)bts[it].pitch));
 			const float4 v0 = p[0], v1 = p[1];
 			const float in[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
 			float o[8];
@@ -723,20 +777,24 @@ __global__ __launch_bounds__(256) void k_encode_pixels(const EncPixArgs a)
 		for (int it = 0; it < TILE_ROUNDS; ++it) {
 			const int t = tid + it * 256;
 			if (t < ntask) {
-				const int pitch = bts[it].pitch;
+				const unsigned pitch = (unsigned)bts[it].pitch;
 				const float *p = tile + bts[it].addr + sub;
-				const float2 *q = &sqf[bts[it].tq & 1][sub];
+				const float4 *q = sqf[bts[it].tq & 1][sub];
 				float in[8], o[8];
 #pragma unroll
 				for (int y = 0; y < 8; ++y) {
-					in[y] = p[y * pitch];
+					in[y] = p[__umul24((unsigned)y, pitch)];
 				}
 				dct1<false>(in, o);
 #pragma unroll
-				for (int u = 0; u < 8; ++u) {
+				for (int u = 0; u < 8; u += 2) {
 					// IEEE divide, round half away from zero (imgproc.c:28)
-					const float qq = quant_divide(o[u], q[u * 8].x, q[u * 8].y);
-					iq[it][u] = round_half_away(qq);
+					const float4 dr = q[u >> 1];
+					const f2 qq = quant_divide(f2{o[u], o[u + 1]}, f2{dr.x, dr.y}, f2{dr.z, dr.w});
+					// round_half_away() on the pair
+					const f2 rr = qq + f2{__builtin_copysignf(0x1.fffffep-2f, qq.x), __builtin_copysignf(0x1.fffffep-2f, qq.y)};
+					iq[it][u] = (int)rr.x;
+					iq[it][u + 1] = (int)rr.y;
 				}
 			}
 		}
@@ -759,14 +817,17 @@ __global__ __launch_bounds__(256) void k_encode_pixels(const EncPixArgs a)
 			}
 		}
 		__syncthreads();                              // every column has been read: the blocks' int16 lines go over the planes
+		uint16_t *zp[8];                              // this thread's places in the line of its block of round 0
+#pragma unroll
+		for (int u = 0; u < 8; ++u) {
+			zp[u] = reinterpret_cast<uint16_t *>(tile) + (tid >> 3) * 64 + zcol[u];
+		}
 #pragma unroll
 		for (int it = 0; it < TILE_ROUNDS; ++it) {
-			const int t = tid + it * 256;
-			if (t < ntask) {
-				uint16_t *line = reinterpret_cast<uint16_t *>(tile) + (t >> 3) * 64;
+			if (tid + it * 256 < ntask) {
 #pragma unroll
 				for (int u = 0; u < 8; ++u) {
-					line[zcol[u]] = (uint16_t)iq[it][u];
+					zp[u][it * 32 * 64] = (uint16_t)iq[it][u];    // block (tid + it * 256) >> 3
 				}
 			}
 		}
@@ -785,8 +846,7 @@ __global__ __launch_bounds__(256) void k_encode_pixels(const EncPixArgs a)
 				const int4 v = stg[t];
 				dst[t] = v;
 				if (a.codes) {
-					reinterpret_cast<uint8_t *>(s5.nzm)[t] = (uint8_t)(nz_pair16(v.x) | (nz_pair16(v.y) << 2) |
-					                                                 (nz_pair16(v.z) << 4) | (nz_pair16(v.w) << 6));
+					reinterpret_cast<uint8_t *>(s5.nzm)[t] = (uint8_t)nz_octet(v);
 				}
 			}
 		}
@@ -927,7 +987,7 @@ __global__ __launch_bounds__(256) void k_selftest_divide(unsigned long long *out
 			for (int sgn = 0; sgn < 2; ++sgn) {
 				float n = __int_as_float(__float_as_int(tie) + nb);
 				n = sgn ? -n : n;
-				const float want = n / d, got = quant_divide(n, d, r1);
+				const float want = n / d, got = quant_divide(n, -d, r1);
 				cases++;
 				if (want != got && !(fabsf(want) < 0.25f && fabsf(got) < 0.25f)) {
 					badq++;
@@ -939,7 +999,7 @@ __global__ __launch_bounds__(256) void k_selftest_divide(unsigned long long *out
 		}
 		h = h * 1664525u + 1013904223u;
 		const float n = (float)((int)(h >> 7) - (1 << 24)) * 0.5f;     // |n| < 2^24, halves included
-		const float want = n / d, got = quant_divide(n, d, r1);
+		const float want = n / d, got = quant_divide(n, -d, r1);
 		cases++;
 		if (want != got && !(fabsf(want) < 0.25f && fabsf(got) < 0.25f)) {
 			badq++;
