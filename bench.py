@@ -361,8 +361,8 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; gloo rehearses the multi-rank path "
                                                       "with several ranks on ONE GPU (RCCL refuses that)")
     ap.add_argument("--one-stream", action="store_true",
-                    help="decode and encode on ONE stream (for rocprofv3 --stats: kernels of the two pipelines then "
-                         "do not overlap and their durations are the ones `kernel_ms` reports)")
+                    help="decode and encode on ONE stream, and the decoder's batch not in halves (for rocprofv3 --stats: "
+                         "kernels then do not overlap and their durations are the ones `kernel_ms` reports)")
     args = ap.parse_args()
     if args.cpu_worker > 0:
         cpu_worker(args.cpu_worker)
@@ -392,6 +392,8 @@ def main():
         dist = dist_mod
     else:
         torch.cuda.set_device(local)
+    if args.one_stream:
+        os.environ["JPEG_AMD_NO_SPLIT"] = "1"              # the decoder's two halves stay on one stream too
     from jpeg_amd import binding, synth, mjpeg
 
     dev = local

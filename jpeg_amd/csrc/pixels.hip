@@ -96,6 +96,13 @@ __device__ __forceinline__ void dct1(const float (&in)[8], float (&out)[8])
 #ifndef TILE_BLOCKS
 #define TILE_BLOCKS 96
 #endif
+#ifndef TILE_PAD
+#define TILE_PAD 4                  // floats behind every plane row: rows start on different banks (keeps 16-byte alignment)
+#endif
+#ifndef LINE_I16
+#define LINE_I16 72                 // int16 from one block's parked zig-zag line to the next: 64 + 8, so that the lines of
+                                    // the eight blocks a wave scatters coefficients into start on different banks
+#endif
 #define TILE_ROUNDS ((TILE_BLOCKS * 8 + 255) / 256)   // rounds of a (block, 1/8 block) stage over 256 threads
 
 // (int)roundf(x) for |x| < 2^31: adding the largest float below one half (with the sign of x) and
@@ -165,7 +172,7 @@ static void make_layout(const JhGeom &g, TileLayout *t)
 	int off = 0;
 	for (int c = 0; c < g.ncomp; ++c) {
 		t->base[c] = off;
-		t->pitch[c] = G * 8 * g.H[c] + 4;   // +4: rows start on different banks, stays 16-byte aligned
+		t->pitch[c] = G * 8 * g.H[c] + TILE_PAD;
 		off += 8 * g.V[c] * t->pitch[c];
 		t->sx_magic[c] = 65536 / g.step_x[c] + 1;
 		t->sy_magic[c] = 65536 / g.step_y[c] + 1;
@@ -303,7 +310,7 @@ __global__ __launch_bounds__(256) void k_decode_pixels(const DecPixArgs a)
 		for (int it = 0; it < TILE_ROUNDS; ++it) {
 			const int t = tid + it * 256;
 			if (t < ntask) {
-				stg[t] = src[t];
+				*reinterpret_cast<int4 *>(reinterpret_cast<int16_t *>(stg) + (t >> 3) * LINE_I16 + (t & 7) * 8) = src[t];
 			}
 		}
 	}
@@ -321,7 +328,7 @@ __global__ __launch_bounds__(256) void k_decode_pixels(const DecPixArgs a)
 		const int16_t *zp[8];                         // the zig-zag places of raster row `sub` in the line of this thread's
 #pragma unroll                                        // block of round 0 (a round on: 32 lines on)
 		for (int x = 0; x < 8; ++x) {
-			zp[x] = reinterpret_cast<const int16_t *>(tile) + (tid >> 3) * 64 + kt.invz[sub * 8 + x];
+			zp[x] = reinterpret_cast<const int16_t *>(tile) + (tid >> 3) * LINE_I16 + kt.invz[sub * 8 + x];
 		}
 		float rowv[TILE_ROUNDS][8];
 #pragma unroll
@@ -335,7 +342,7 @@ __global__ __launch_bounds__(256) void k_decode_pixels(const DecPixArgs a)
 				for (int x = 0; x < 8; ++x) {
 					const int q = (int)((x & 1) ? (qs[x >> 1] >> 16) : (qs[x >> 1] & 0xffffu));
 					// int32 product, then int -> float; |c| < 2^15 and q < 2^16: the 24-bit multiply is exact
-					in[x] = (float)__mul24((int)zp[x][it * 32 * 64], q);
+					in[x] = (float)__mul24((int)zp[x][it * 32 * LINE_I16], q);
 				}
 				dct1<true>(in, rowv[it]);
 			}
@@ -623,7 +630,7 @@ struct Stage5 {
 	uint16_t actab[2][256];
 	uint16_t acfix[2][2];
 };
-#define STAGE5_OFF (TILE_BLOCKS * 128)             // bytes: behind the lines of a full tile
+#define STAGE5_OFF (TILE_BLOCKS * LINE_I16 * 2)             // bytes: behind the lines of a full tile
 
 // NF = 1: one plane, no sub-sampling.  NF = 3: luma at full resolution, both chroma planes
 // down-sampled SX x SY (what read_image() sets up: luma H x V, chroma 1 x 1; encoder.c:109-146).
@@ -691,9 +698,13 @@ __global__ __launch_bounds__(256) void k_encode_pixels(const EncPixArgs a)
 							// frame_to_ycc (frame.c:168-170): double arithmetic, left to right, rounded to
 							// float.  Padding pixels keep their raw RGB values (loops stop at X, Y: quirk Q7).
 							const float R = s[i][0], G_ = s[i][1], B_ = s[i][2];
-							const float Yl = 0.299 * R + 0.587 * G_ + 0.114 * B_;
-							const float Cb = - 0.1687 * R - 0.3313 * G_ + 0.5 * B_ + shift;
-							const float Cr = 0.5 * R - 0.4187 * G_ - 0.0813 * B_ + shift;
+							// The products with 0.5 are exact (a power of two), so `t + 0.5 * B` and `0.5 * R - t` round
+							// once either way: written as fused operations they cost one instruction instead of two
+							// and give the same binary64 value.  Every other product rounds on its own, as in C.
+							const double Rd = R, Gd = G_, Bd = B_;
+							const float Yl = 0.299 * Rd + 0.587 * Gd + 0.114 * Bd;
+							const float Cb = __builtin_fma(0.5, Bd, - 0.1687 * Rd - 0.3313 * Gd) + shift;
+							const float Cr = __builtin_fma(0.5, Rd, -(0.4187 * Gd)) - 0.0813 * Bd + shift;
 							s[i][0] = Yl;
 							s[i][1] = Cb;
 							s[i][2] = Cr;
@@ -820,14 +831,14 @@ __global__ __launch_bounds__(256) void k_encode_pixels(const EncPixArgs a)
 		uint16_t *zp[8];                              // this thread's places in the line of its block of round 0
 #pragma unroll
 		for (int u = 0; u < 8; ++u) {
-			zp[u] = reinterpret_cast<uint16_t *>(tile) + (tid >> 3) * 64 + zcol[u];
+			zp[u] = reinterpret_cast<uint16_t *>(tile) + (tid >> 3) * LINE_I16 + zcol[u];
 		}
 #pragma unroll
 		for (int it = 0; it < TILE_ROUNDS; ++it) {
 			if (tid + it * 256 < ntask) {
 #pragma unroll
 				for (int u = 0; u < 8; ++u) {
-					zp[u][it * 32 * 64] = (uint16_t)iq[it][u];    // block (tid + it * 256) >> 3
+					zp[u][it * 32 * LINE_I16] = (uint16_t)iq[it][u];    // block (tid + it * 256) >> 3
 				}
 			}
 		}
@@ -843,7 +854,7 @@ __global__ __launch_bounds__(256) void k_encode_pixels(const EncPixArgs a)
 		for (int it = 0; it < TILE_ROUNDS; ++it) {
 			const int t = tid + it * 256;
 			if (t < ntask) {
-				const int4 v = stg[t];
+				const int4 v = *reinterpret_cast<const int4 *>(reinterpret_cast<const int16_t *>(stg) + (t >> 3) * LINE_I16 + (t & 7) * 8);
 				dst[t] = v;
 				if (a.codes) {
 					reinterpret_cast<uint8_t *>(s5.nzm)[t] = (uint8_t)nz_octet(v);
@@ -881,23 +892,24 @@ __global__ __launch_bounds__(256) void k_encode_pixels(const EncPixArgs a)
 			const int ta = kt.kta[k];
 			const uint16_t *T = s5.actab[ta];
 			const unsigned eob = s5.acfix[ta][0], zrl = s5.acfix[ta][1];
-			const int16_t *line = reinterpret_cast<const int16_t *>(tile) + b * 64 + h * 32;
+			const int16_t *line = reinterpret_cast<const int16_t *>(tile) + b * LINE_I16 + h * 32;
 			const unsigned long long map = s5.nzm[b];
 			const unsigned lo = (unsigned)map & ~1u, hi = (unsigned)(map >> 32);
 			unsigned m = h ? hi : lo;
 			// position (inside this half) of the nonzero coefficient before the first of this half; DC counts as one
 			int prev = h ? (31 - __builtin_clz(lo | 1u)) - 32 : 0;
 			unsigned bits = 0, tprev = 0;
-			int z = m ? __builtin_ctz(m) : 0;
+			// (bit 31 ORed in: an empty map reads coefficient 31 for nothing instead of taking a compare and a select)
+			int z = __builtin_ctz(m | 0x80000000u);
 			int c = line[z];
 			while (m) {
 				m &= m - 1;
-				const int zn = m ? __builtin_ctz(m) : 0;
+				const int zn = __builtin_ctz(m | 0x80000000u);
 				const int cn = line[zn];
 				const int run = z - prev - 1;
 				prev = z;
 				const int cat = __builtin_amdgcn_frexp_expf((float)c);  // bits of |c| (encode_cat, coeffs.c:56-74)
-				bits += tprev + (unsigned)(run >> 4) * zrl;
+				bits += tprev + __umul24((unsigned)(run >> 4), zrl);    // 24-bit: the 32-bit multiply runs at a quarter of the rate
 				tprev = T[((run & 15) << 4) | cat];
 				z = zn;
 				c = cn;
@@ -913,7 +925,7 @@ __global__ __launch_bounds__(256) void k_encode_pixels(const EncPixArgs a)
 	if (tid < nb) {
 		const unsigned bits = s5.pbits[0][tid] + s5.pbits[1][tid];
 		const size_t blk = (size_t)f * g.nblk + (size_t)(my * g.m_x + mx0) * B + tid;
-		const unsigned dc = (unsigned)(uint16_t)reinterpret_cast<const int16_t *>(tile)[tid * 64];
+		const unsigned dc = (unsigned)(uint16_t)reinterpret_cast<const int16_t *>(tile)[tid * LINE_I16];
 		a.nzmap[blk] = s5.nzm[tid];
 		a.acdc[blk] = (bits >= 0x4000u ? JH_ACBITS_NOCODE : bits) | (dc << 16);
 	}

@@ -7,8 +7,9 @@ rounds on its own.  Checked without a GPU, on what hipcc makes of jpeg_amd/csrc/
     (quant_reciprocal / quant_divide: the steps of the correctly rounded division, which ARE fused in hipcc's
     own expansion of `/`);
   * ISA: the decode kernels for one and three components hold no fused instruction at all; the four-component
-    kernel only inside the expansion of its three divisions (frame.c:208-210); no kernel fuses in binary64;
-    every encode kernel holds exactly as many binary32 FMAs as its IR has fma calls."""
+    kernel only inside the expansion of its three divisions (frame.c:208-210); no decode kernel fuses in binary64;
+    every encode kernel holds exactly as many FMAs, binary32 and binary64, as its IR has fma calls (binary64: the two
+    products with 0.5 of frame_to_ycc, frame.c:169-170 -- exact products, so fused or not is the same value)."""
 import os
 import re
 import shutil
@@ -71,16 +72,20 @@ def test_isa_fuses_only_what_the_source_fuses(built):
     assert len(isa) >= 10 and set(isa) == set(funcs)
     for name, lines in isa.items():
         n32 = sum((2 if m.group(1) == "v_pk_fma_f32" else 1) for m in (FUSED32.match(l) for l in lines) if m)
-        assert not any(FUSED64.match(l) for l in lines), name
+        n64 = sum(1 for l in lines if FUSED64.match(l))
         ndiv = sum(1 for l in lines if re.match(r"^\s*v_div_fmas_f32\b", l))
         if "k_decode_pixels" in name:
             if "ILi4E" in name:                        # YCCK: three divisions per pixel, FMAs only inside their expansion
                 assert ndiv > 0 and n32 <= 5 * ndiv, (name, n32, ndiv)
             else:
                 assert n32 == 0 and ndiv == 0, (name, n32)
+            assert n64 == 0, name
         else:
             body = funcs[name]
             # explicit fmaf() calls of the source, as scalars or gathered into vectors by the SLP vectoriser
             want = len(re.findall(r"call[^\n]*@llvm\.fma\.f32", body)) + \
                 sum(int(n) for n in re.findall(r"call[^\n]*@llvm\.fma\.v(\d+)f32", body))
             assert want > 0 and n32 == want and ndiv == 0, (name, n32, want)
+            want64 = len(re.findall(r"call[^\n]*@llvm\.fma\.f64", body))
+            assert n64 == want64 and want64 == (0 if "ILi1E" in name else 2 * 4 * 2 if re.search(r"ILi3ELi\dELi2E", name) else 2 * 4), \
+                (name, n64, want64)                     # two per pixel, four pixels per row, one or two rows unrolled
