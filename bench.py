@@ -361,8 +361,8 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; gloo rehearses the multi-rank path "
                                                       "with several ranks on ONE GPU (RCCL refuses that)")
     ap.add_argument("--one-stream", action="store_true",
-                    help="decode and encode on ONE stream, and the decoder's batch not in halves (for rocprofv3 --stats: "
-                         "kernels then do not overlap and their durations are the ones `kernel_ms` reports)")
+                    help="decode and encode on ONE stream (for rocprofv3 --stats: kernels of the two pipelines then "
+                         "do not overlap and their durations are the ones `kernel_ms` reports)")
     args = ap.parse_args()
     if args.cpu_worker > 0:
         cpu_worker(args.cpu_worker)
@@ -392,8 +392,6 @@ def main():
         dist = dist_mod
     else:
         torch.cuda.set_device(local)
-    if args.one_stream:
-        os.environ["JPEG_AMD_NO_SPLIT"] = "1"              # the decoder's two halves stay on one stream too
     from jpeg_amd import binding, synth, mjpeg
 
     dev = local
@@ -496,6 +494,21 @@ def main():
         assert ms["matches_single_process_totals"], ms
         res["mjpeg_stream_1080p_422_q85"] = ms
         mjpeg.release_stream_decoders()
+
+    if rank == 0 and world == 1 and not args.no_workloads:
+        # Decode alone with the batch issued as two halves on two streams (jpeg_hip_decoder_set_split): what a
+        # decode-only job gets.  Last of the GPU measurements: the extra stream takes a share of the process's
+        # hardware queues while it exists, and the two-pipeline step and the Motion JPEG stream lose by that.
+        dec3 = binding.Decoder(dev)
+        dec3.set_split(True)
+        dec3.prepare(jpgs)
+        out3 = dec3.alloc_output()
+        dec3.run(out3)
+        assert all(s == 0 for s in dec3.sync())
+        t3 = timed(torch, lambda: dec3.run(out3), args.steps, 1, None)
+        res["decode_mpix_s_two_halves"] = round(F * pix * args.steps / t3 / 1e6, 1)
+        dec3.close()
+        del out3
 
     if rank == 0 and world == 1 and not args.no_cpu:
         res["cpu_baseline"] = cpu_baseline(cpu_imgs, cpu_jpgs, cfg)

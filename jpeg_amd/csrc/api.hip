@@ -243,7 +243,7 @@ struct jpeg_hip_decoder {
 	int debug = 0;
 	bool tolerant = false;
 	bool coefs_only = false;          // run() stops behind the Huffman passes (jpeg_hip_read_scan)
-	bool no_split = false;            // JPEG_AMD_NO_SPLIT=1: one stream for the whole batch (measurements)
+	bool split = false;               // jpeg_hip_decoder_set_split() / JPEG_AMD_SPLIT=1: batches go out as two halves
 	bool all_scans_tried = false;     // sync() has prepared this batch again with every scan found on the host
 	StageTimer timer;
 
@@ -290,17 +290,14 @@ extern "C" int jpeg_hip_decoder_create(jpeg_hip_decoder **dec, int device)
 	jpeg_hip_decoder *d = new jpeg_hip_decoder();
 	d->device = device;
 	{
-		const char *e = getenv("JPEG_AMD_NO_SPLIT");
-		d->no_split = e && *e && *e != '0';
+		const char *e = getenv("JPEG_AMD_SPLIT");
+		d->split = e && *e && *e != '0';
 	}
 	d->pass.reserve(JH_MAX_PASSES);                        // addresses of the passes stay put (see cap)
 	memset(&d->g, 0, sizeof d->g);
 	if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&d->copy_stream, hipStreamNonBlocking) != hipSuccess ||
 	    hipEventCreateWithFlags(&d->uploaded, hipEventDisableTiming) != hipSuccess ||
-	    hipEventCreateWithFlags(&d->done, hipEventDisableTiming) != hipSuccess ||
-	    hipStreamCreateWithFlags(&d->half_stream, hipStreamNonBlocking) != hipSuccess ||
-	    hipEventCreateWithFlags(&d->forked, hipEventDisableTiming) != hipSuccess ||
-	    hipEventCreateWithFlags(&d->joined, hipEventDisableTiming) != hipSuccess) {
+	    hipEventCreateWithFlags(&d->done, hipEventDisableTiming) != hipSuccess) {
 		jpeg_hip_decoder_destroy(d);
 		return RET_FAILURE_MEMORY_ALLOCATION;
 	}
@@ -1033,10 +1030,13 @@ static int decoder_launch_frames(jpeg_hip_decoder *dec, int f0, int n, hipStream
 	return RET_SUCCESS;
 }
 
-// A batch of JH_SPLIT_MIN frames or more goes out as two halves, the second on a stream of the decoder's own
-// that forks from s and joins it again: the pipeline of one half ends in narrow kernels (k_huff_survivors,
-// k_huff_walk, k_huff_emit run a few workgroups per frame), and the wide kernels of the other half fill the
-// chip meanwhile (+9 % on 128 frames of 4K).  The halves share nothing they write.
+// On request (jpeg_hip_decoder_set_split) a batch of JH_SPLIT_MIN frames or more goes out as two halves, the
+// second on a stream of the decoder's own that forks from s and joins it again: the pipeline of one half ends
+// in narrow kernels (k_huff_survivors, k_huff_walk, k_huff_emit run a few workgroups per frame), and the wide
+// kernels of the other half fill the chip meanwhile (128 frames of 4K: 154 -> 165 Gpix/s).  The halves share
+// nothing they write.  Off by default: it pays where the decoder has the GPU to itself; beside an encoder on
+// another stream or a second decoder's upload the extra stream competes for the few hardware queues a process
+// has (the two-pipeline step 99.5 -> 93.1 Gpix/s, Motion JPEG 62 k -> 43 k frames/s).
 // Not split: batches timed kernel by kernel (the stages of one stream are what the events bracket).
 #define JH_SPLIT_MIN 16
 
@@ -1049,7 +1049,23 @@ static int decoder_launch(jpeg_hip_decoder *dec, hipStream_t s)
 			return RET_FAILURE_LOGIC_ERROR;
 		}
 	}
-	const bool split = dec->nframes >= JH_SPLIT_MIN && !dec->timer.on && !dec->no_split;
+	bool split = dec->split && dec->nframes >= JH_SPLIT_MIN && !dec->timer.on;
+	if (split && !dec->half_stream) {
+		// Made when first wanted: a process has few hardware queues (four by default), and a stream that exists
+		// takes its turn on them whether it is used or not -- beside a decoder that does not split it would only
+		// put another decoder's upload and this one's kernels on one queue.
+		hipStream_t hs = nullptr;
+		if (hipStreamCreateWithFlags(&hs, hipStreamNonBlocking) != hipSuccess ||
+		    hipEventCreateWithFlags(&dec->forked, hipEventDisableTiming) != hipSuccess ||
+		    hipEventCreateWithFlags(&dec->joined, hipEventDisableTiming) != hipSuccess) {
+			if (hs) {
+				hipStreamDestroy(hs);
+			}
+			split = false;                                 // one stream will do
+		} else {
+			dec->half_stream = hs;
+		}
+	}
 	if (!split) {
 		if (int err = decoder_launch_frames(dec, 0, dec->nframes, s, &th)) {
 			return err;
@@ -1339,6 +1355,11 @@ extern "C" void jpeg_hip_decoder_set_debug(jpeg_hip_decoder *dec, int flags)
 	for (DecPass &ps : dec->pass) {
 		ps.work.debug = flags;
 	}
+}
+
+extern "C" void jpeg_hip_decoder_set_split(jpeg_hip_decoder *dec, int on)
+{
+	dec->split = on != 0;
 }
 
 extern "C" void jpeg_hip_decoder_set_tolerant(jpeg_hip_decoder *dec, int on)

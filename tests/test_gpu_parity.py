@@ -839,10 +839,10 @@ def test_components_coded_more_than_once(hip, oracle):
 
 
 @pytest.mark.parametrize("n", [15, 16, 17, 33])
-def test_batch_that_goes_out_as_two_halves(hip, oracle, n, monkeypatch):
-    """From 16 frames on run() puts the second half of the batch on a stream of its own (api.hip decoder_launch):
-    frames of both halves, the odd one in the middle, damaged ones on either side, coefficients and states per
-    frame -- all as the oracle has them, and as one stream for the whole batch (JPEG_AMD_NO_SPLIT) gives them."""
+def test_batch_that_goes_out_as_two_halves(hip, oracle, n):
+    """With set_split() run() puts the second half of a batch of 16 frames and more on a stream of its own (api.hip
+    decoder_launch): frames of both halves, the odd one in the middle, damaged ones on either side, coefficients
+    and states per frame -- all as the oracle has them, and as one stream for the whole batch gives them."""
     imgs = [synth_image(176, 112, 3, 8, seed=300 + i, frame=i) for i in range(n)]
     jpgs = []
     for i, im in enumerate(imgs):
@@ -853,30 +853,29 @@ def test_batch_that_goes_out_as_two_halves(hip, oracle, n, monkeypatch):
         jpgs.append(j)
     want = [oracle.decode(j) for j in jpgs]
 
-    def run():
+    def run(split, files):
         d = hip.Decoder()
         try:
-            d.prepare(jpgs)
+            d.set_split(split)
+            d.prepare(files)
             out = d.run()
             st = d.sync()
             return st, d.to_arrays(out), [d.coefficients(f) for f in range(n)]
         finally:
             d.close()
 
-    st, px, coefs = run()
+    st, px, coefs = run(True, jpgs)
     assert [s & 0xFFFFFFFF for s in st] == [w[0] & 0xFFFFFFFF for w in want]
     for f in range(n):
         _assert_coefs(coefs[f], want[f][2])
         assert np.array_equal(px[f], want[f][1]), f
-    monkeypatch.setenv("JPEG_AMD_NO_SPLIT", "1")
-    st1, px1, coefs1 = run()
+    st1, px1, coefs1 = run(False, jpgs)
     assert st1 == st
     assert all(np.array_equal(a, b) for a, b in zip(px, px1))
     # frames coded as one scan per component: the coefficient buffer is cleared before the halves part
-    monkeypatch.delenv("JPEG_AMD_NO_SPLIT")
     multi = [oracle.encode_scans(im, P=8, H=2, V=1, q=80, optimize=0, restart_interval=(i % 3) * 2, split=0)[1]
              for i, im in enumerate(imgs)]
-    outs, st = hip.decode(multi)
+    st, px, _ = run(True, multi)
     assert st == [0] * n
-    for j, o in zip(multi, outs):
+    for j, o in zip(multi, px):
         assert np.array_equal(o, oracle.decode(j)[1])
