@@ -153,6 +153,13 @@ void jpeg_hip_decoder_set_debug(jpeg_hip_decoder *dec, int flags);
  * APP10, APP15, DNL and JPGn segments (decoder.c:654-656); prepare() does the same by default.  on != 0
  * (before prepare()): such segments are skipped by their length instead.  No counterpart in the reference. */
 void jpeg_hip_decoder_set_tolerant(jpeg_hip_decoder *dec, int on);
+/* on != 0: prepare() queues the upload of the codestreams on `stream` (the stream run() will be given: stream
+ * order then takes the place of the event run() waits for) instead of a copy stream of the decoder's own.  For
+ * pipelines that keep a decoder per stream -- jpeg_amd/mjpeg.py decode_stream: the upload of one batch runs beside
+ * the kernels of the other decoder's batch, and so do the narrow ends of the two batches' kernels; the process
+ * then has two busy streams instead of one and two copy streams (a process has four hardware queues).  The stream
+ * must outlive the decoder's use of it.  No counterpart in the reference. */
+void jpeg_hip_decoder_set_upload_stream(jpeg_hip_decoder *dec, void *stream, int on);
 /* on != 0: run() issues a batch of 16 frames or more as two halves, the second on a stream of the decoder's own
  * that forks from and joins the caller's stream (the narrow synchronisation kernels of one half overlap the wide
  * kernels of the other: +7 % where the decoder has the GPU to itself; costs throughput beside other streams of the

@@ -235,6 +235,10 @@ struct jpeg_hip_decoder {
 	size_t last_stride = 0;
 	hipStream_t last_stream = nullptr;
 	hipStream_t copy_stream = nullptr;    // the codestreams' DMA runs here, beside the kernels of another decoder
+	                                      // (made by the first prepare() that wants it: a stream that exists takes
+	                                      // one of the process's few hardware queues, used or not)
+	hipStream_t up_stream = nullptr;      // ... or on this stream of the caller's (jpeg_hip_decoder_set_upload_stream)
+	bool up_user = false;
 	hipEvent_t uploaded = nullptr;        // ... and run() makes its stream wait for this
 	hipEvent_t done = nullptr;            // end of run()'s kernels: sync() waits for it, not for the whole stream
 	hipStream_t half_stream = nullptr;    // run() puts the second half of a batch here (see decoder_launch)
@@ -295,7 +299,7 @@ extern "C" int jpeg_hip_decoder_create(jpeg_hip_decoder **dec, int device)
 	}
 	d->pass.reserve(JH_MAX_PASSES);                        // addresses of the passes stay put (see cap)
 	memset(&d->g, 0, sizeof d->g);
-	if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&d->copy_stream, hipStreamNonBlocking) != hipSuccess ||
+	if (hipSetDevice(device) != hipSuccess ||
 	    hipEventCreateWithFlags(&d->uploaded, hipEventDisableTiming) != hipSuccess ||
 	    hipEventCreateWithFlags(&d->done, hipEventDisableTiming) != hipSuccess) {
 		jpeg_hip_decoder_destroy(d);
@@ -780,6 +784,10 @@ static int decoder_prepare(jpeg_hip_decoder *dec, int nframes, const uint8_t *co
 		lap("pass alloc");
 	}
 
+	if (!dec->up_user && !dec->copy_stream) {
+		HIPCHK(hipStreamCreateWithFlags(&dec->copy_stream, hipStreamNonBlocking));
+	}
+	const hipStream_t ups = dec->up_user ? dec->up_stream : dec->copy_stream;
 	HIPCHK(dec->grow((void **)&dec->d_raw, dec->raw_bytes));
 	HIPCHK(dec->grow((void **)&dec->d_quant, nframes * sizeof(JhQuant)));
 	HIPCHK(dec->grow((void **)&dec->d_coefs, (size_t)nframes * G.nblk * 64 * sizeof(int16_t)));
@@ -787,10 +795,10 @@ static int decoder_prepare(jpeg_hip_decoder *dec, int nframes, const uint8_t *co
 		// one DMA from the caller's pinned memory, on the decoder's copy stream; run() waits for it on its stream
 		const size_t span = (size_t)(span_hi - span_lo);
 		if (lead) {
-			HIPCHK(hipMemsetAsync(dec->d_raw, 0, lead, dec->copy_stream));
+			HIPCHK(hipMemsetAsync(dec->d_raw, 0, lead, ups));
 		}
-		HIPCHK(hipMemcpyAsync(dec->d_raw + lead, span_lo, span, hipMemcpyHostToDevice, dec->copy_stream));
-		HIPCHK(hipMemsetAsync(dec->d_raw + lead + span, 0, dec->raw_bytes - lead - span, dec->copy_stream));
+		HIPCHK(hipMemcpyAsync(dec->d_raw + lead, span_lo, span, hipMemcpyHostToDevice, ups));
+		HIPCHK(hipMemsetAsync(dec->d_raw + lead + span, 0, dec->raw_bytes - lead - span, ups));
 		for (int f = 0; f < nframes; ++f) {
 			dec->file_ptr[f] = jpg[f];                         // sync() reads headers there: valid until it has returned
 		}
@@ -852,7 +860,7 @@ static int decoder_prepare(jpeg_hip_decoder *dec, int nframes, const uint8_t *co
 			}
 			const size_t a = file_off[piece_first(pc)], b = pc + 1 < npiece ? file_off[piece_first(pc + 1)] : total;
 			if (up == hipSuccess && b > a) {
-				up = hipMemcpyAsync(dec->d_raw + a, stage + a, b - a, hipMemcpyHostToDevice, dec->copy_stream);
+				up = hipMemcpyAsync(dec->d_raw + a, stage + a, b - a, hipMemcpyHostToDevice, ups);
 			}
 		}
 		for (std::thread &th : pool) {
@@ -863,7 +871,7 @@ static int decoder_prepare(jpeg_hip_decoder *dec, int nframes, const uint8_t *co
 			dec->file_ptr[f] = stage + file_off[f];
 		}
 	}
-	HIPCHK(hipEventRecord(dec->uploaded, dec->copy_stream));
+	HIPCHK(hipEventRecord(dec->uploaded, ups));
 	HIPCHK(hipMemcpy(dec->d_quant, quant.data(), nframes * sizeof(JhQuant), hipMemcpyHostToDevice));
 	lap("upload");
 
@@ -1355,6 +1363,12 @@ extern "C" void jpeg_hip_decoder_set_debug(jpeg_hip_decoder *dec, int flags)
 	for (DecPass &ps : dec->pass) {
 		ps.work.debug = flags;
 	}
+}
+
+extern "C" void jpeg_hip_decoder_set_upload_stream(jpeg_hip_decoder *dec, void *stream, int on)
+{
+	dec->up_user = on != 0;
+	dec->up_stream = on ? (hipStream_t)stream : nullptr;
 }
 
 extern "C" void jpeg_hip_decoder_set_split(jpeg_hip_decoder *dec, int on)

@@ -70,15 +70,17 @@ def decode_batches(frames, batch=256, device=0):
 
 
 def decode_stream(frames, batch=256, device=0):
-    """The same, pipelined: two decoder objects take turns.  A helper thread parses the
-    next batch's headers and queues its upload (copy stream of the decoder: a DMA from the library's pinned
-    staging buffer, or straight from the caller's memory when `frames` is a binding.PinnedFrames) while the
-    kernels of this batch run; and the kernels of batch i+1 are queued behind those of batch i BEFORE the caller
-    waits for batch i, so the device does not idle while Python looks at statuses.  Yields (tensor, status) in
-    order; the tensor of a batch stays valid until the batch after the next one has been yielded."""
+    """The same, pipelined: two decoder objects take turns, each on a stream of its own.
+    A helper thread parses the next batch's headers and queues its upload on that decoder's stream (a DMA from the
+    library's pinned staging buffer, or straight from the caller's memory when `frames` is a binding.PinnedFrames)
+    while the kernels of this batch run on the other stream; and the kernels of batch i+1 are queued BEFORE the
+    caller waits for batch i, so the device does not idle while Python looks at statuses, and the narrow kernels
+    at the end of one batch's synchronisation run beside the wide ones of the other.  Two busy streams and no copy
+    streams: a process has four hardware queues.  Yields (tensor, status) in order; the tensor of a batch stays
+    valid until the batch after the next one has been yielded."""
     from concurrent.futures import ThreadPoolExecutor
     torch = binding._torch()
-    decs, stream = _stream_decoders(device)
+    decs, streams = _stream_decoders(device)
     chunks = [frames[i:i + batch] for i in range(0, len(frames), batch)]
     if not chunks:
         return
@@ -87,7 +89,7 @@ def decode_stream(frames, batch=256, device=0):
         try:
             fut.result()
             fut = None
-            with torch.cuda.stream(stream):
+            with torch.cuda.stream(streams[0]):
                 out = decs[0].run()
             for i in range(len(chunks)):
                 d, nxt = decs[i & 1], decs[(i + 1) & 1]
@@ -99,7 +101,7 @@ def decode_stream(frames, batch=256, device=0):
                     else:
                         fut.result()
                         fut = None
-                    with torch.cuda.stream(stream):
+                    with torch.cuda.stream(streams[(i + 1) & 1]):
                         out_next = nxt.run()
                 st = d.sync()                      # waits for batch i only (an event behind its last kernel)
                 if i + 2 < len(chunks):
@@ -118,7 +120,7 @@ _stream_state = {}
 
 
 def _stream_decoders(device):
-    """The two decoder objects and the stream of decode_stream(), kept between calls: their pinned staging
+    """The two decoder objects and their streams of decode_stream(), kept between calls: their pinned staging
     buffers and device workspaces only grow, and making them anew costs more than decoding a few thousand
     frames (hipHostMalloc of 150 MB pins every page).  release_stream_decoders() frees them."""
     if device not in _stream_state:
@@ -126,7 +128,11 @@ def _stream_decoders(device):
         if not _stream_state:
             import atexit
             atexit.register(release_stream_decoders)   # while the HIP runtime is still there
-        _stream_state[device] = ([binding.Decoder(device), binding.Decoder(device)], torch.cuda.Stream(device=device))
+        decs = [binding.Decoder(device), binding.Decoder(device)]
+        streams = [torch.cuda.Stream(device=device), torch.cuda.Stream(device=device)]
+        for d, st in zip(decs, streams):
+            d.set_upload_stream(st)
+        _stream_state[device] = (decs, streams)
     return _stream_state[device]
 
 
