@@ -495,21 +495,6 @@ def main():
         res["mjpeg_stream_1080p_422_q85"] = ms
         mjpeg.release_stream_decoders()
 
-    if rank == 0 and world == 1 and not args.no_workloads:
-        # Decode alone with the batch issued as two halves on two streams (jpeg_hip_decoder_set_split): what a
-        # decode-only job gets.  Last of the GPU measurements: the extra stream takes a share of the process's
-        # hardware queues while it exists, and the two-pipeline step and the Motion JPEG stream lose by that.
-        dec3 = binding.Decoder(dev)
-        dec3.set_split(True)
-        dec3.prepare(jpgs)
-        out3 = dec3.alloc_output()
-        dec3.run(out3)
-        assert all(s == 0 for s in dec3.sync())
-        t3 = timed(torch, lambda: dec3.run(out3), args.steps, 1, None)
-        res["decode_mpix_s_two_halves"] = round(F * pix * args.steps / t3 / 1e6, 1)
-        dec3.close()
-        del out3
-
     if rank == 0 and world == 1 and not args.no_cpu:
         res["cpu_baseline"] = cpu_baseline(cpu_imgs, cpu_jpgs, cfg)
         if not args.no_mjpeg:

@@ -160,12 +160,6 @@ void jpeg_hip_decoder_set_tolerant(jpeg_hip_decoder *dec, int on);
  * then has two busy streams instead of one and two copy streams (a process has four hardware queues).  The stream
  * must outlive the decoder's use of it.  No counterpart in the reference. */
 void jpeg_hip_decoder_set_upload_stream(jpeg_hip_decoder *dec, void *stream, int on);
-/* on != 0: run() issues a batch of 16 frames or more as two halves, the second on a stream of the decoder's own
- * that forks from and joins the caller's stream (the narrow synchronisation kernels of one half overlap the wide
- * kernels of the other: +7 % where the decoder has the GPU to itself; costs throughput beside other streams of the
- * process, which is why it is off by default; JPEG_AMD_SPLIT=1 in the environment turns it on for every decoder).
- * Results are the same either way.  No counterpart in the reference. */
-void jpeg_hip_decoder_set_split(jpeg_hip_decoder *dec, int on);
 /* compressed bytes actually consumed per frame (entropy-coded segment incl. RSTn), for roofline accounting */
 int  jpeg_hip_decoder_ecs_bytes(const jpeg_hip_decoder *dec, size_t *ecs_len);
 

@@ -31,7 +31,7 @@ EXPORTS = [
     "jpeg_hip_decoder_info", "jpeg_hip_decoder_frame_bytes", "jpeg_hip_decoder_run",
     "jpeg_hip_decoder_sync", "jpeg_hip_decoder_get_coefficients", "jpeg_hip_decoder_set_timing",
     "jpeg_hip_decoder_get_timing", "jpeg_hip_decoder_ecs_bytes", "jpeg_hip_decoder_get_stats",
-    "jpeg_hip_decoder_set_debug", "jpeg_hip_decoder_get_chain_steps", "jpeg_hip_decoder_set_tolerant", "jpeg_hip_decoder_set_split", "jpeg_hip_decoder_set_upload_stream", "jpeg_hip_mjpeg_split",
+    "jpeg_hip_decoder_set_debug", "jpeg_hip_decoder_get_chain_steps", "jpeg_hip_decoder_set_tolerant", "jpeg_hip_decoder_set_upload_stream", "jpeg_hip_mjpeg_split",
     "jpeg_hip_encoder_create", "jpeg_hip_encoder_destroy", "jpeg_hip_encoder_configure",
     "jpeg_hip_encoder_info", "jpeg_hip_encoder_run", "jpeg_hip_encoder_sync",
     "jpeg_hip_encoder_get_jpeg", "jpeg_hip_encoder_device_jpeg", "jpeg_hip_encoder_get_coefficients",
@@ -126,8 +126,6 @@ def lib():
         L.jpeg_hip_decoder_get_stats.argtypes = [vp, C.c_int, C.POINTER(C.c_uint32)]
         L.jpeg_hip_decoder_set_debug.argtypes = [vp, C.c_int]
         L.jpeg_hip_decoder_set_debug.restype = None
-        L.jpeg_hip_decoder_set_split.argtypes = [vp, C.c_int]
-        L.jpeg_hip_decoder_set_split.restype = None
         L.jpeg_hip_decoder_set_upload_stream.argtypes = [vp, vp, C.c_int]
         L.jpeg_hip_decoder_set_upload_stream.restype = None
         L.jpeg_hip_decoder_set_tolerant.argtypes = [vp, C.c_int]
@@ -355,10 +353,6 @@ class Decoder:
         else:
             self.L.jpeg_hip_decoder_set_upload_stream(self.h, C.c_void_p(stream.cuda_stream), 1)
         self._upload_stream = stream                     # keeps it alive
-
-    def set_split(self, on=True):
-        """Batches of 16 frames and more as two halves on two streams (decode-only workloads; see jpeg_amd.h)."""
-        self.L.jpeg_hip_decoder_set_split(self.h, int(on))
 
     def set_tolerant(self, on=True):
         """Skip APP9/APP10/APP15/DNL/JPGn segments instead of failing like the reference (call before prepare)."""

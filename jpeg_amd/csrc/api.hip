@@ -241,13 +241,10 @@ struct jpeg_hip_decoder {
 	bool up_user = false;
 	hipEvent_t uploaded = nullptr;        // ... and run() makes its stream wait for this
 	hipEvent_t done = nullptr;            // end of run()'s kernels: sync() waits for it, not for the whole stream
-	hipStream_t half_stream = nullptr;    // run() puts the second half of a batch here (see decoder_launch)
-	hipEvent_t forked = nullptr, joined = nullptr;
 	bool ran = false;
 	int debug = 0;
 	bool tolerant = false;
 	bool coefs_only = false;          // run() stops behind the Huffman passes (jpeg_hip_read_scan)
-	bool split = false;               // jpeg_hip_decoder_set_split() / JPEG_AMD_SPLIT=1: batches go out as two halves
 	bool all_scans_tried = false;     // sync() has prepared this batch again with every scan found on the host
 	StageTimer timer;
 
@@ -293,10 +290,6 @@ extern "C" int jpeg_hip_decoder_create(jpeg_hip_decoder **dec, int device)
 	}
 	jpeg_hip_decoder *d = new jpeg_hip_decoder();
 	d->device = device;
-	{
-		const char *e = getenv("JPEG_AMD_SPLIT");
-		d->split = e && *e && *e != '0';
-	}
 	d->pass.reserve(JH_MAX_PASSES);                        // addresses of the passes stay put (see cap)
 	memset(&d->g, 0, sizeof d->g);
 	if (hipSetDevice(device) != hipSuccess ||
@@ -316,9 +309,6 @@ extern "C" void jpeg_hip_decoder_destroy(jpeg_hip_decoder *dec)
 		if (dec->copy_stream) {
 			hipStreamSynchronize(dec->copy_stream);
 		}
-		if (dec->half_stream) {
-			hipStreamSynchronize(dec->half_stream);
-		}
 		dec->release();
 		if (dec->h_stage) {
 			hipHostFree(dec->h_stage);
@@ -329,17 +319,8 @@ extern "C" void jpeg_hip_decoder_destroy(jpeg_hip_decoder *dec)
 		if (dec->done) {
 			hipEventDestroy(dec->done);
 		}
-		if (dec->forked) {
-			hipEventDestroy(dec->forked);
-		}
-		if (dec->joined) {
-			hipEventDestroy(dec->joined);
-		}
 		if (dec->copy_stream) {
 			hipStreamDestroy(dec->copy_stream);
-		}
-		if (dec->half_stream) {
-			hipStreamDestroy(dec->half_stream);
 		}
 		delete dec;
 	}
@@ -1006,48 +987,6 @@ __global__ void k_dec_init(JhDecState *st, int n)
 	}
 }
 
-// Frames f0 ... f0 + n - 1 of the batch, all passes and the pixel kernel, on stream s.  Every per-frame array of
-// the work is either indexed by the frame (frames, state, coefficients, quantisation tables, samples: shifted
-// here) or reached through the absolute offsets JhDecFrame holds.
-static int decoder_launch_frames(jpeg_hip_decoder *dec, int f0, int n, hipStream_t s, const JhTimerHook *th)
-{
-	const size_t frame_coefs = (size_t)dec->g.nblk * 64;
-	for (DecPass &ps : dec->pass) {
-		JhDecodeWork w = ps.work;
-		w.frames += f0;
-		w.state += f0;
-		w.coefs += f0 * frame_coefs;
-		w.nframes = n;
-		hipLaunchKernelGGL(k_dec_init, dim3((n + 63) / 64), dim3(64), 0, s, w.state, n);
-		if (jh_launch_ecs_unstuff(w, s, th)) {
-			return RET_FAILURE_LOGIC_ERROR;
-		}
-		if (jh_launch_huff_decode(w, ps.g, s, th)) {
-			return RET_FAILURE_LOGIC_ERROR;
-		}
-	}
-	if (dec->coefs_only) {
-		return RET_SUCCESS;                                // jpeg_hip_read_scan: the coefficients are the result
-	}
-	dec->timer.begin("k_decode_pixels", s);
-	if (jh_launch_decode_pixels(dec->g, n, dec->d_coefs + f0 * frame_coefs, dec->d_quant + f0,
-	                            (uint8_t *)dec->last_out + f0 * dec->last_stride, dec->last_stride, s)) {
-		return RET_FAILURE_LOGIC_ERROR;
-	}
-	dec->timer.end(s);
-	return RET_SUCCESS;
-}
-
-// On request (jpeg_hip_decoder_set_split) a batch of JH_SPLIT_MIN frames or more goes out as two halves, the
-// second on a stream of the decoder's own that forks from s and joins it again: the pipeline of one half ends
-// in narrow kernels (k_huff_survivors, k_huff_walk, k_huff_emit run a few workgroups per frame), and the wide
-// kernels of the other half fill the chip meanwhile (128 frames of 4K: 154 -> 165 Gpix/s).  The halves share
-// nothing they write.  Off by default: it pays where the decoder has the GPU to itself; beside an encoder on
-// another stream or a second decoder's upload the extra stream competes for the few hardware queues a process
-// has (the two-pipeline step 99.5 -> 93.1 Gpix/s, Motion JPEG 62 k -> 43 k frames/s).
-// Not split: batches timed kernel by kernel (the stages of one stream are what the events bracket).
-#define JH_SPLIT_MIN 16
-
 static int decoder_launch(jpeg_hip_decoder *dec, hipStream_t s)
 {
 	const JhTimerHook th = dec->timer.hook();
@@ -1057,46 +996,24 @@ static int decoder_launch(jpeg_hip_decoder *dec, hipStream_t s)
 			return RET_FAILURE_LOGIC_ERROR;
 		}
 	}
-	bool split = dec->split && dec->nframes >= JH_SPLIT_MIN && !dec->timer.on;
-	if (split && !dec->half_stream) {
-		// Made when first wanted: a process has few hardware queues (four by default), and a stream that exists
-		// takes its turn on them whether it is used or not -- beside a decoder that does not split it would only
-		// put another decoder's upload and this one's kernels on one queue.
-		hipStream_t hs = nullptr;
-		if (hipStreamCreateWithFlags(&hs, hipStreamNonBlocking) != hipSuccess ||
-		    hipEventCreateWithFlags(&dec->forked, hipEventDisableTiming) != hipSuccess ||
-		    hipEventCreateWithFlags(&dec->joined, hipEventDisableTiming) != hipSuccess) {
-			if (hs) {
-				hipStreamDestroy(hs);
-			}
-			split = false;                                 // one stream will do
-		} else {
-			dec->half_stream = hs;
+	for (DecPass &ps : dec->pass) {
+		hipLaunchKernelGGL(k_dec_init, dim3((dec->nframes + 63) / 64), dim3(64), 0, s, ps.d_state, dec->nframes);
+		if (jh_launch_ecs_unstuff(ps.work, s, &th)) {
+			return RET_FAILURE_LOGIC_ERROR;
+		}
+		if (jh_launch_huff_decode(ps.work, ps.g, s, &th)) {
+			return RET_FAILURE_LOGIC_ERROR;
 		}
 	}
-	if (!split) {
-		if (int err = decoder_launch_frames(dec, 0, dec->nframes, s, &th)) {
-			return err;
-		}
+	if (dec->coefs_only) {
+		// jpeg_hip_read_scan: the coefficients are the result
 		return hipEventRecord(dec->done, s) == hipSuccess ? RET_SUCCESS : RET_FAILURE_LOGIC_ERROR;
 	}
-	const int n0 = (dec->nframes + 1) / 2;
-	if (hipEventRecord(dec->forked, s) != hipSuccess || hipStreamWaitEvent(dec->half_stream, dec->forked, 0) != hipSuccess) {
+	dec->timer.begin("k_decode_pixels", s);
+	if (jh_launch_decode_pixels(dec->g, dec->nframes, dec->d_coefs, dec->d_quant, dec->last_out, dec->last_stride, s)) {
 		return RET_FAILURE_LOGIC_ERROR;
 	}
-	int err = decoder_launch_frames(dec, n0, dec->nframes - n0, dec->half_stream, &th);
-	// whatever happened, s takes the other stream's work back in before anything else is said
-	const bool rejoined = hipEventRecord(dec->joined, dec->half_stream) == hipSuccess;
-	if (!err) {
-		err = decoder_launch_frames(dec, 0, n0, s, &th);
-	}
-	if (!rejoined || hipStreamWaitEvent(s, dec->joined, 0) != hipSuccess) {
-		hipStreamSynchronize(dec->half_stream);
-		return RET_FAILURE_LOGIC_ERROR;
-	}
-	if (err) {
-		return err;
-	}
+	dec->timer.end(s);
 	return hipEventRecord(dec->done, s) == hipSuccess ? RET_SUCCESS : RET_FAILURE_LOGIC_ERROR;
 }
 
@@ -1369,11 +1286,6 @@ extern "C" void jpeg_hip_decoder_set_upload_stream(jpeg_hip_decoder *dec, void *
 {
 	dec->up_user = on != 0;
 	dec->up_stream = on ? (hipStream_t)stream : nullptr;
-}
-
-extern "C" void jpeg_hip_decoder_set_split(jpeg_hip_decoder *dec, int on)
-{
-	dec->split = on != 0;
 }
 
 extern "C" void jpeg_hip_decoder_set_tolerant(jpeg_hip_decoder *dec, int on)

@@ -70,57 +70,53 @@ def decode_batches(frames, batch=256, device=0):
 
 
 def decode_stream(frames, batch=256, device=0):
-    """The same, pipelined: two decoder objects take turns, each on a stream of its own.
-    A helper thread parses the next batch's headers and queues its upload on that decoder's stream (a DMA from the
-    library's pinned staging buffer, or straight from the caller's memory when `frames` is a binding.PinnedFrames)
-    while the kernels of this batch run on the other stream; and the kernels of batch i+1 are queued BEFORE the
-    caller waits for batch i, so the device does not idle while Python looks at statuses, and the narrow kernels
-    at the end of one batch's synchronisation run beside the wide ones of the other.  Two busy streams and no copy
+    """The same, pipelined: STREAM_DEPTH decoder objects take turns, each on a stream of
+    its own.  A helper thread parses the next batches' headers and queues their upload on that decoder's stream (a
+    DMA from the library's pinned staging buffer, or straight from the caller's memory when `frames` is a
+    binding.PinnedFrames) while the kernels of this batch run on another stream; and the kernels of batch i+1 are
+    queued BEFORE the caller waits for batch i, so the device does not idle while Python looks at statuses, and
+    the narrow kernels at the end of one batch's synchronisation run beside the wide ones of the next.  No copy
     streams: a process has four hardware queues.  Yields (tensor, status) in order; the tensor of a batch stays
     valid until the batch after the next one has been yielded."""
     from concurrent.futures import ThreadPoolExecutor
     torch = binding._torch()
     decs, streams = _stream_decoders(device)
+    n = len(decs)
     chunks = [frames[i:i + batch] for i in range(0, len(frames), batch)]
     if not chunks:
         return
     with ThreadPoolExecutor(max_workers=1) as pool:
-        fut = pool.submit(decs[0].prepare, chunks[0])
+        futs = {}                                  # batch -> its prepare() in the helper thread
+        outs = {}                                  # batch -> its output tensor, queued
         try:
-            fut.result()
-            fut = None
-            with torch.cuda.stream(streams[0]):
-                out = decs[0].run()
+            for j in range(min(n, len(chunks))):
+                futs[j] = pool.submit(decs[j % n].prepare, chunks[j])
             for i in range(len(chunks)):
-                d, nxt = decs[i & 1], decs[(i + 1) & 1]
-                out_next = None
-                if i + 1 < len(chunks):
-                    # batch i+1 was prepared while batch i-1 ran (or just now, for i = 0)
-                    if i == 0:
-                        nxt.prepare(chunks[1])
-                    else:
-                        fut.result()
-                        fut = None
-                    with torch.cuda.stream(streams[(i + 1) & 1]):
-                        out_next = nxt.run()
-                st = d.sync()                      # waits for batch i only (an event behind its last kernel)
-                if i + 2 < len(chunks):
-                    fut = pool.submit(d.prepare, chunks[i + 2])    # d is free again: its batch is done
-                yield out, st
-                out = out_next
+                # batch i + 1 is queued before batch i is waited for (its prepare() is awaited if need be), and so
+                # are the batches behind it, up to n - 1 ahead, if they happen to be prepared already
+                for j in range(i, min(i + n, len(chunks))):
+                    if j not in outs and j in futs and (j <= i + 1 or futs[j].done()):
+                        futs.pop(j).result()
+                        with torch.cuda.stream(streams[j % n]):
+                            outs[j] = decs[j % n].run()
+                st = decs[i % n].sync()            # waits for batch i only (an event behind its last kernel)
+                if i + n < len(chunks):
+                    futs[i + n] = pool.submit(decs[i % n].prepare, chunks[i + n])   # that decoder is free again
+                yield outs.pop(i), st
         finally:
-            if fut is not None:
+            for fut in futs.values():
                 try:
-                    fut.result()                   # a consumer that stops early: let the helper finish its batch
+                    fut.result()                   # a consumer that stops early: let the helper finish its batches
                 except binding.JpegError:
                     pass
 
 
 _stream_state = {}
+STREAM_DEPTH = int(__import__("os").environ.get("JPEG_AMD_STREAM_DEPTH", "3"))   # decoders (and streams) that take turns
 
 
 def _stream_decoders(device):
-    """The two decoder objects and their streams of decode_stream(), kept between calls: their pinned staging
+    """The decoder objects and their streams of decode_stream(), kept between calls: their pinned staging
     buffers and device workspaces only grow, and making them anew costs more than decoding a few thousand
     frames (hipHostMalloc of 150 MB pins every page).  release_stream_decoders() frees them."""
     if device not in _stream_state:
@@ -128,8 +124,8 @@ def _stream_decoders(device):
         if not _stream_state:
             import atexit
             atexit.register(release_stream_decoders)   # while the HIP runtime is still there
-        decs = [binding.Decoder(device), binding.Decoder(device)]
-        streams = [torch.cuda.Stream(device=device), torch.cuda.Stream(device=device)]
+        decs = [binding.Decoder(device) for _ in range(STREAM_DEPTH)]
+        streams = [torch.cuda.Stream(device=device) for _ in range(STREAM_DEPTH)]
         for d, st in zip(decs, streams):
             d.set_upload_stream(st)
         _stream_state[device] = (decs, streams)

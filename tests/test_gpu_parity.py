@@ -836,46 +836,3 @@ def test_components_coded_more_than_once(hip, oracle):
         outs, st = hip.decode([jga, twice, jgb])
         assert st[0] == 0 and st[2] == 0 and st[1] == 0x1001
         assert np.array_equal(outs[0], oracle.decode(jga)[1]) and np.array_equal(outs[2], oracle.decode(jgb)[1])
-
-
-@pytest.mark.parametrize("n", [15, 16, 17, 33])
-def test_batch_that_goes_out_as_two_halves(hip, oracle, n):
-    """With set_split() run() puts the second half of a batch of 16 frames and more on a stream of its own (api.hip
-    decoder_launch): frames of both halves, the odd one in the middle, damaged ones on either side, coefficients
-    and states per frame -- all as the oracle has them, and as one stream for the whole batch gives them."""
-    imgs = [synth_image(176, 112, 3, 8, seed=300 + i, frame=i) for i in range(n)]
-    jpgs = []
-    for i, im in enumerate(imgs):
-        err, j, _ = oracle.encode(im, P=8, H=2, V=2, q=50 + (i * 7) % 50, optimize=i % 2, restart_interval=(0, 5, 0, 1)[i % 4])
-        assert err == 0
-        if i in (3, n // 2, n - 2):
-            j = j[:len(j) * 2 // 3] + b"\xff\xd9"          # the data runs out inside an MCU
-        jpgs.append(j)
-    want = [oracle.decode(j) for j in jpgs]
-
-    def run(split, files):
-        d = hip.Decoder()
-        try:
-            d.set_split(split)
-            d.prepare(files)
-            out = d.run()
-            st = d.sync()
-            return st, d.to_arrays(out), [d.coefficients(f) for f in range(n)]
-        finally:
-            d.close()
-
-    st, px, coefs = run(True, jpgs)
-    assert [s & 0xFFFFFFFF for s in st] == [w[0] & 0xFFFFFFFF for w in want]
-    for f in range(n):
-        _assert_coefs(coefs[f], want[f][2])
-        assert np.array_equal(px[f], want[f][1]), f
-    st1, px1, coefs1 = run(False, jpgs)
-    assert st1 == st
-    assert all(np.array_equal(a, b) for a, b in zip(px, px1))
-    # frames coded as one scan per component: the coefficient buffer is cleared before the halves part
-    multi = [oracle.encode_scans(im, P=8, H=2, V=1, q=80, optimize=0, restart_interval=(i % 3) * 2, split=0)[1]
-             for i, im in enumerate(imgs)]
-    st, px, _ = run(True, multi)
-    assert st == [0] * n
-    for j, o in zip(multi, px):
-        assert np.array_equal(o, oracle.decode(j)[1])
