@@ -455,7 +455,6 @@ def main():
         res["decode_mpix_s_at_%d_frames" % (2 * F)] = round(2 * F * pix * n2 / t2 / 1e6, 1)
         dec2.close()
         del out2
-
     if rank == 0:
         # ---- roofline of the dominant kernel, live HIP-event timing on the launch stream ----
         kd = kernel_times(dec, lambda: dec.run(out), torch)
@@ -494,6 +493,35 @@ def main():
         assert ms["matches_single_process_totals"], ms
         res["mjpeg_stream_1080p_422_q85"] = ms
         mjpeg.release_stream_decoders()
+
+    if rank == 0 and world == 1 and not args.no_workloads:
+        # What a decode-only job gets that lays the metric's F frames out over three decoder objects with a stream
+        # each (the narrow kernels of one part beside the wide ones of the others; a process has four hardware
+        # queues, so three such streams and no encoder beside them is as far as this goes).  Last of the GPU
+        # measurements: HIP maps streams to its hardware queues as they are first used, and the Motion JPEG
+        # pipeline above, measured after this, found its three streams serialised (46 k instead of 72 k frames/s).
+        third = (F + 2) // 3
+        parts = [jpgs[k:k + third] for k in range(0, F, third)]
+        decs3, outs3 = [], []
+        for js in parts:
+            dd = binding.Decoder(dev)
+            dd.prepare(js)
+            decs3.append(dd)
+            outs3.append(dd.alloc_output())
+        streams3 = [torch.cuda.Stream(dev) for _ in parts]
+
+        def decode3():
+            for dd, oo, ss in zip(decs3, outs3, streams3):
+                with torch.cuda.stream(ss):
+                    dd.run(oo)
+
+        decode3()
+        assert all(s == 0 for dd in decs3 for s in dd.sync())
+        t3 = timed(torch, decode3, args.steps, 1, None)
+        res["decode_mpix_s_three_decoders"] = round(F * pix * args.steps / t3 / 1e6, 1)
+        for dd in decs3:
+            dd.close()
+        del outs3
 
     if rank == 0 and world == 1 and not args.no_cpu:
         res["cpu_baseline"] = cpu_baseline(cpu_imgs, cpu_jpgs, cfg)

@@ -193,6 +193,8 @@ struct DecPass {
 	unsigned long long *d_drop = nullptr;
 	JhDecFrame *d_frames = nullptr;
 	JhDecState *d_state = nullptr;
+	JhDecState *h_state = nullptr;    // page-locked: run() ends with a copy of the states into it, on its stream
+	size_t h_state_cap = 0;
 	JhHuffLut *d_luts = nullptr;
 	std::vector<JhHuffLut> luts;
 	size_t cs_off = 0, seg_off = 0, chunk_off = 0, sub_off = 0, wg_off = 0;
@@ -207,11 +209,18 @@ struct DecPass {
 		hipFree(d_start); hipFree(d_frames); hipFree(d_state); hipFree(d_luts);
 		hipFree(d_rec); hipFree(d_meta); hipFree(d_surv); hipFree(d_key01); hipFree(d_wg_agg); hipFree(d_wg_base); hipFree(d_prec); hipFree(d_wg_key); hipFree(d_drop);
 		d_drop = nullptr;
+		if (h_state) {
+			hipHostFree(h_state);
+		}
+		h_state = nullptr;
+		h_state_cap = 0;
 		d_cs = nullptr; d_seg = d_chunk_kept = d_chunk_rst = nullptr;
 		d_start = nullptr; d_frames = nullptr; d_state = nullptr; d_luts = nullptr;
 		d_rec = d_prec = nullptr; d_meta = nullptr; d_surv = nullptr; d_key01 = nullptr; d_wg_agg = d_wg_base = nullptr; d_wg_key = nullptr;
 	}
 };
+
+#define JH_UPLOAD_PIECE (8u << 20)     // bytes per DMA of a batch that is uploaded from caller-pinned memory
 
 struct jpeg_hip_decoder {
 	int device = 0;
@@ -563,6 +572,13 @@ static int decoder_prepare(jpeg_hip_decoder *dec, int nframes, const uint8_t *co
 		dec->pass.back().release();
 		dec->pass.pop_back();
 	}
+	// Everything prepare() puts on the device goes through ONE stream -- the caller's (set_upload_stream) or the
+	// decoder's copy stream -- and nothing through the null stream: that one shares a hardware queue with some
+	// other stream of the process, and a blocking call on it waits for whatever that stream has queued.
+	if (!dec->up_user && !dec->copy_stream) {
+		HIPCHK(hipStreamCreateWithFlags(&dec->copy_stream, hipStreamNonBlocking));
+	}
+	const hipStream_t ups = dec->up_user ? dec->up_stream : dec->copy_stream;
 	dec->pass.resize(pass_comp.size());
 	for (size_t pi = 0; pi < pass_comp.size(); ++pi) {
 		DecPass &ps = dec->pass[pi];
@@ -749,36 +765,52 @@ static int decoder_prepare(jpeg_hip_decoder *dec, int nframes, const uint8_t *co
 		HIPCHK(dec->grow((void **)&ps.d_wg_key, wg_entries * sizeof(unsigned long long)));
 		HIPCHK(dec->grow((void **)&ps.d_wg_agg, wg_entries * sizeof(JhWgAgg)));
 		HIPCHK(dec->grow((void **)&ps.d_wg_base, wg_entries * sizeof(JhWgAgg)));
-		HIPCHK(hipMemset(ps.d_meta, 0, sub_entries * sizeof(uint32_t)));
-		HIPCHK(hipMemset(ps.d_wg_agg, 0, wg_entries * sizeof(JhWgAgg)));
-		HIPCHK(hipMemset(ps.d_wg_base, 0, wg_entries * sizeof(JhWgAgg)));
+		HIPCHK(hipMemsetAsync(ps.d_meta, 0, sub_entries * sizeof(uint32_t), ups));
+		HIPCHK(hipMemsetAsync(ps.d_wg_agg, 0, wg_entries * sizeof(JhWgAgg), ups));
+		HIPCHK(hipMemsetAsync(ps.d_wg_base, 0, wg_entries * sizeof(JhWgAgg), ups));
 		HIPCHK(dec->grow((void **)&ps.d_frames, nframes * sizeof(JhDecFrame)));
 		HIPCHK(dec->grow((void **)&ps.d_state, nframes * sizeof(JhDecState)));
 		HIPCHK(dec->grow((void **)&ps.d_luts, ps.luts.size() * sizeof(JhHuffLut)));
-		HIPCHK(hipMemset(ps.d_cs, 0, cs_bytes));
-		HIPCHK(hipMemset(ps.d_seg, 0, seg_entries * 4));
+		HIPCHK(hipMemsetAsync(ps.d_cs, 0, cs_bytes, ups));
+		HIPCHK(hipMemsetAsync(ps.d_seg, 0, seg_entries * 4, ups));
 		HIPCHK(dec->grow((void **)&ps.d_drop, seg_entries * sizeof(unsigned long long)));
-		HIPCHK(hipMemset(ps.d_drop, 0, seg_entries * sizeof(unsigned long long)));
-		HIPCHK(hipMemcpy(ps.d_frames, ps.frames.data(), nframes * sizeof(JhDecFrame), hipMemcpyHostToDevice));
-		HIPCHK(hipMemcpy(ps.d_luts, ps.luts.data(), ps.luts.size() * sizeof(JhHuffLut), hipMemcpyHostToDevice));
+		HIPCHK(hipMemsetAsync(ps.d_drop, 0, seg_entries * sizeof(unsigned long long), ups));
+		// (from pageable memory that stays as it is until the stream has been waited for below)
+		HIPCHK(hipMemcpyAsync(ps.d_frames, ps.frames.data(), nframes * sizeof(JhDecFrame), hipMemcpyHostToDevice, ups));
+		HIPCHK(hipMemcpyAsync(ps.d_luts, ps.luts.data(), ps.luts.size() * sizeof(JhHuffLut), hipMemcpyHostToDevice, ups));
+		if (ps.h_state_cap < (size_t)nframes) {
+			if (ps.h_state) {
+				hipHostFree(ps.h_state);
+				ps.h_state = nullptr;
+				ps.h_state_cap = 0;
+			}
+			const size_t want = (size_t)nframes + (size_t)nframes / 4 + 16;
+			HIPCHK(hipHostMalloc((void **)&ps.h_state, want * sizeof(JhDecState), hipHostMallocDefault));
+			ps.h_state_cap = want;
+		}
 		ps.work.rm = rm;
 		lap("pass alloc");
 	}
 
-	if (!dec->up_user && !dec->copy_stream) {
-		HIPCHK(hipStreamCreateWithFlags(&dec->copy_stream, hipStreamNonBlocking));
-	}
-	const hipStream_t ups = dec->up_user ? dec->up_stream : dec->copy_stream;
 	HIPCHK(dec->grow((void **)&dec->d_raw, dec->raw_bytes));
 	HIPCHK(dec->grow((void **)&dec->d_quant, nframes * sizeof(JhQuant)));
 	HIPCHK(dec->grow((void **)&dec->d_coefs, (size_t)nframes * G.nblk * 64 * sizeof(int16_t)));
+	HIPCHK(hipMemcpyAsync(dec->d_quant, quant.data(), nframes * sizeof(JhQuant), hipMemcpyHostToDevice, ups));
+	// The tables and zeroed work areas are small; the host arrays they come from may go once this returns.  The
+	// stream holds nothing else of this decoder: its last batch has been waited for.
+	HIPCHK(hipStreamSynchronize(ups));
 	if (direct) {
 		// one DMA from the caller's pinned memory, on the decoder's copy stream; run() waits for it on its stream
 		const size_t span = (size_t)(span_hi - span_lo);
 		if (lead) {
 			HIPCHK(hipMemsetAsync(dec->d_raw, 0, lead, ups));
 		}
-		HIPCHK(hipMemcpyAsync(dec->d_raw + lead, span_lo, span, hipMemcpyHostToDevice, ups));
+		// in pieces: streams share the process's few hardware queues, and whatever shares one with this stream
+		// would wait for a single copy of a hundred megabytes from its first byte to its last
+		for (size_t at = 0; at < span; at += JH_UPLOAD_PIECE) {
+			const size_t n = span - at < JH_UPLOAD_PIECE ? span - at : (size_t)JH_UPLOAD_PIECE;
+			HIPCHK(hipMemcpyAsync(dec->d_raw + lead + at, span_lo + at, n, hipMemcpyHostToDevice, ups));
+		}
 		HIPCHK(hipMemsetAsync(dec->d_raw + lead + span, 0, dec->raw_bytes - lead - span, ups));
 		for (int f = 0; f < nframes; ++f) {
 			dec->file_ptr[f] = jpg[f];                         // sync() reads headers there: valid until it has returned
@@ -853,7 +885,6 @@ static int decoder_prepare(jpeg_hip_decoder *dec, int nframes, const uint8_t *co
 		}
 	}
 	HIPCHK(hipEventRecord(dec->uploaded, ups));
-	HIPCHK(hipMemcpy(dec->d_quant, quant.data(), nframes * sizeof(JhQuant), hipMemcpyHostToDevice));
 	lap("upload");
 
 	for (DecPass &ps : dec->pass) {
@@ -1005,15 +1036,19 @@ static int decoder_launch(jpeg_hip_decoder *dec, hipStream_t s)
 			return RET_FAILURE_LOGIC_ERROR;
 		}
 	}
-	if (dec->coefs_only) {
-		// jpeg_hip_read_scan: the coefficients are the result
-		return hipEventRecord(dec->done, s) == hipSuccess ? RET_SUCCESS : RET_FAILURE_LOGIC_ERROR;
+	if (!dec->coefs_only) {                                // jpeg_hip_read_scan: the coefficients are the result
+		dec->timer.begin("k_decode_pixels", s);
+		if (jh_launch_decode_pixels(dec->g, dec->nframes, dec->d_coefs, dec->d_quant, dec->last_out, dec->last_stride, s)) {
+			return RET_FAILURE_LOGIC_ERROR;
+		}
+		dec->timer.end(s);
 	}
-	dec->timer.begin("k_decode_pixels", s);
-	if (jh_launch_decode_pixels(dec->g, dec->nframes, dec->d_coefs, dec->d_quant, dec->last_out, dec->last_stride, s)) {
-		return RET_FAILURE_LOGIC_ERROR;
+	// the frames' states come back on the same stream, into page-locked memory: sync() needs the event only
+	for (DecPass &ps : dec->pass) {
+		if (hipMemcpyAsync(ps.h_state, ps.d_state, dec->nframes * sizeof(JhDecState), hipMemcpyDeviceToHost, s) != hipSuccess) {
+			return RET_FAILURE_LOGIC_ERROR;
+		}
 	}
-	dec->timer.end(s);
 	return hipEventRecord(dec->done, s) == hipSuccess ? RET_SUCCESS : RET_FAILURE_LOGIC_ERROR;
 }
 
@@ -1048,7 +1083,7 @@ extern "C" int jpeg_hip_decoder_sync(jpeg_hip_decoder *dec, int *frame_status)
 	HIPCHK(hipEventSynchronize(dec->done));                // this run's kernels, not what the caller queued behind them
 	for (int attempt = 0;; ++attempt) {
 		for (DecPass &ps : dec->pass) {
-			HIPCHK(hipMemcpy(ps.state.data(), ps.d_state, dec->nframes * sizeof(JhDecState), hipMemcpyDeviceToHost));
+			memcpy(ps.state.data(), ps.h_state, dec->nframes * sizeof(JhDecState));   // run() brought them over
 		}
 		// The restart-segment tables are sized from DRI.  The reference never looks at Ri (quirk Q1): the
 		// markers decide, and a file may hold more of them than its header promised (or none was sent).

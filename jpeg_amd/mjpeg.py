@@ -113,6 +113,10 @@ def decode_stream(frames, batch=256, device=0):
 
 _stream_state = {}
 STREAM_DEPTH = int(__import__("os").environ.get("JPEG_AMD_STREAM_DEPTH", "3"))   # decoders (and streams) that take turns
+# 0 = normal.  A process that has had many streams busy before may find these three on ONE hardware queue (HIP maps
+# streams to its four queues as they are first used) and the pipeline serialised: 46 k instead of 72 k frames/s
+# measured; -1 (high priority: another set of queues) brought that case back to 67 - 73 k.  DESIGN.md section 5.
+STREAM_PRIORITY = int(__import__("os").environ.get("JPEG_AMD_STREAM_PRIORITY", "0"))
 
 
 def _stream_decoders(device):
@@ -125,7 +129,7 @@ def _stream_decoders(device):
             import atexit
             atexit.register(release_stream_decoders)   # while the HIP runtime is still there
         decs = [binding.Decoder(device) for _ in range(STREAM_DEPTH)]
-        streams = [torch.cuda.Stream(device=device) for _ in range(STREAM_DEPTH)]
+        streams = [torch.cuda.Stream(device=device, priority=STREAM_PRIORITY) for _ in range(STREAM_DEPTH)]
         for d, st in zip(decs, streams):
             d.set_upload_stream(st)
         _stream_state[device] = (decs, streams)
