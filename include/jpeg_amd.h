@@ -157,8 +157,10 @@ void jpeg_hip_decoder_set_tolerant(jpeg_hip_decoder *dec, int on);
  * order then takes the place of the event run() waits for) instead of a copy stream of the decoder's own.  For
  * pipelines that keep a decoder per stream -- jpeg_amd/mjpeg.py decode_stream: the upload of one batch runs beside
  * the kernels of the other decoder's batch, and so do the narrow ends of the two batches' kernels; the process
- * then has two busy streams instead of one and two copy streams (a process has four hardware queues).  The stream
- * must outlive the decoder's use of it.  No counterpart in the reference. */
+ * then has a busy stream per decoder and no copy streams (a process has four hardware queues).  prepare() waits
+ * on that stream for the tables and cleared work areas it queues there (small; the stream should hold nothing but
+ * this decoder's work) and returns with the DMA of the codestreams in flight.  The stream must outlive the
+ * decoder's use of it.  No counterpart in the reference. */
 void jpeg_hip_decoder_set_upload_stream(jpeg_hip_decoder *dec, void *stream, int on);
 /* compressed bytes actually consumed per frame (entropy-coded segment incl. RSTn), for roofline accounting */
 int  jpeg_hip_decoder_ecs_bytes(const jpeg_hip_decoder *dec, size_t *ecs_len);
