@@ -836,3 +836,48 @@ def test_components_coded_more_than_once(hip, oracle):
         outs, st = hip.decode([jga, twice, jgb])
         assert st[0] == 0 and st[2] == 0 and st[1] == 0x1001
         assert np.array_equal(outs[0], oracle.decode(jga)[1]) and np.array_equal(outs[2], oracle.decode(jgb)[1])
+
+
+def test_pipelined_stream_with_batches_that_are_decoded_again(hip, oracle):
+    """mjpeg.decode_stream: three decoders, each with a stream on which its upload and its kernels run
+    (jpeg_hip_decoder_set_upload_stream), the frames' states coming back in page-locked memory at the end of run().
+    Batches that make sync() decode again go through the same machinery: restart markers the header does not
+    announce (segment tables grown), a stray marker in the data (cut out on the host copy), data that ends inside an
+    MCU; and a damaged frame leaves its neighbours alone.  Pageable frames and frames in one page-locked buffer."""
+    from jpeg_amd import mjpeg
+    frames = []
+    for i in range(14):
+        img = synth_image(208, 112, 3, 8, seed=500 + i, frame=i)
+        err, j, _ = oracle.encode(img, P=8, H=2, V=1, q=70 + i, optimize=0, restart_interval=(0, 1, 4)[i % 3])
+        assert err == 0
+        if i % 3 == 1:
+            dri = j.index(b"\xff\xdd")
+            j = j[:dri + 4] + b"\x7f\xff" + j[dri + 6:]      # DRI promises next to no markers: far more come
+        if i == 5:
+            j = j[:len(j) * 3 // 5] + b"\xff\xd9"               # the data runs out
+        if i == 9:
+            at = _ecs_mid(j)
+            j = j[:at] + b"\xff\xe3\x00\x04ab" + j[at:]         # an APP3 segment in the middle of the data
+        frames.append(j)
+    want = [oracle.decode(j) for j in frames]
+    pinned = hip.PinnedFrames.from_frames(frames)
+    for src in (frames, pinned, frames):
+        k = 0
+        for out, st in mjpeg.decode_stream(src, batch=3):
+            px = out.cpu().numpy()
+            for f in range(px.shape[0]):
+                assert st[f] & 0xFFFFFFFF == want[k][0] & 0xFFFFFFFF, (k, hex(st[f]))
+                if want[k][0] == 0:
+                    assert np.array_equal(px[f].reshape(want[k][1].shape), want[k][1]), k
+                k += 1
+        assert k == len(frames)
+    pinned.buf.close()
+
+
+def _ecs_mid(jpg):
+    """a place in the middle of the entropy-coded data that is not inside a stuffed byte or a marker"""
+    sos = jpg.index(b"\xff\xda")
+    at = sos + 2 + ((jpg[sos + 2] << 8) | jpg[sos + 3]) + (len(jpg) - sos) // 2
+    while jpg[at - 1] == 0xFF or jpg[at] == 0xFF:
+        at += 1
+    return at
