@@ -421,7 +421,7 @@ __global__ __launch_bounds__(256) void k_decode_pixels(const DecPixArgs a)
 				fetch4<0>(tile, L, g, c, row, px0, s[c]);
 			}
 		}
-		int res[4 * oc];
+		float ov[4 * oc];                         // the four pixels' samples before rounding
 #pragma unroll
 		for (int i = 0; i < 4; ++i) {
 			float o[oc];
@@ -446,16 +446,39 @@ __global__ __launch_bounds__(256) void k_decode_pixels(const DecPixArgs a)
 			}
 #pragma unroll
 			for (int c = 0; c < oc; ++c) {
-				// (int)roundf(x) clamped to [0, maxval] (frame.c:375-380).  Rounding is monotonic and the bounds
-				// are integers, so clamping first gives the same sample; then round_half_away() on x >= 0
-				const float y = __builtin_amdgcn_fmed3f(o[c], 0.f, maxvalf);
-				res[i * oc + c] = (int)(y + 0x1.fffffep-2f);
+				ov[i * oc + c] = o[c];
 			}
 		}
 		const int npx = min(4, X - gx0);
+		uint8_t *p = org + (__umul24((unsigned)row, rowbytes) + __umul24((unsigned)px0, pxbytes));
+		const bool whole = npx == 4 && ((reinterpret_cast<uintptr_t>(p) & 3) == 0);
+		if (g.P == 8 && whole) {
+			// (int)roundf(x) clamped to [0, 255] (frame.c:375-380) as v_cvt_pk_u8_f32 of floor(x + 0.49999997): the
+			// instruction saturates at both ends and puts the byte where it belongs in the word (it rounds to
+			// nearest by itself, hence the floor: a whole number converts as it is).  Below zero floor(x + c) <= 0
+			// gives 0, as clamping first does; above 255 both give 255; in between it is round_half_away() on x >= 0.
+			uint32_t *pw = reinterpret_cast<uint32_t *>(p);
+#pragma unroll
+			for (int wd = 0; wd < oc; ++wd) {
+				unsigned wv = 0;
+#pragma unroll
+				for (int b = 0; b < 4; ++b) {
+					wv = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_floorf(ov[4 * wd + b] + 0x1.fffffep-2f), (unsigned)b, wv);
+				}
+				pw[wd] = wv;
+			}
+			continue;
+		}
+		int res[4 * oc];
+#pragma unroll
+		for (int n = 0; n < 4 * oc; ++n) {
+			// (int)roundf(x) clamped to [0, maxval] (frame.c:375-380).  Rounding is monotonic and the bounds
+			// are integers, so clamping first gives the same sample; then round_half_away() on x >= 0
+			const float y = __builtin_amdgcn_fmed3f(ov[n], 0.f, maxvalf);
+			res[n] = (int)(y + 0x1.fffffep-2f);
+		}
 		if (g.sample_bytes == 1) {
-			uint8_t *p = org + (__umul24((unsigned)row, rowbytes) + __umul24((unsigned)px0, pxbytes));
-			if (npx == 4 && ((reinterpret_cast<uintptr_t>(p) & 3) == 0)) {
+			if (whole) {
 				uint32_t *pw = reinterpret_cast<uint32_t *>(p);
 #pragma unroll
 				for (int wd = 0; wd < oc; ++wd) {
@@ -476,8 +499,7 @@ __global__ __launch_bounds__(256) void k_decode_pixels(const DecPixArgs a)
 			}
 		} else {
 			// big-endian 16-bit samples (htons, frame.c:386)
-			uint8_t *p = org + (__umul24((unsigned)row, rowbytes) + __umul24((unsigned)px0, pxbytes));
-			if (npx == 4 && ((reinterpret_cast<uintptr_t>(p) & 3) == 0)) {
+			if (whole) {
 				uint32_t *pw = reinterpret_cast<uint32_t *>(p);
 #pragma unroll
 				for (int wd = 0; wd < 2 * oc; ++wd) {
