@@ -881,3 +881,27 @@ def _ecs_mid(jpg):
     while jpg[at - 1] == 0xFF or jpg[at] == 0xFF:
         at += 1
     return at
+
+
+def test_upload_on_a_stream_of_the_callers(hip, oracle):
+    """jpeg_hip_decoder_set_upload_stream: the upload queued on the caller's stream, run() on the same stream or on
+    another one (it waits for the upload by event either way), then back to the decoder's own copy stream; one
+    decoder object through all of it, batches of different sizes."""
+    import torch
+    imgs = [synth_image(144, 80, 3, 8, seed=700 + i, frame=i) for i in range(7)]
+    jpgs = [oracle.encode(im, P=8, H=2, V=2, q=65 + 4 * i, optimize=i % 2, restart_interval=(0, 3)[i % 2])[1] for i, im in enumerate(imgs)]
+    want = [oracle.decode(j)[1] for j in jpgs]
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    d = hip.Decoder()
+    try:
+        for up, run_on, part in ((s1, s1, jpgs[:5]), (s1, s2, jpgs[2:]), (None, s2, jpgs[:3]), (s2, s2, jpgs)):
+            d.set_upload_stream(up)
+            d.prepare(part)
+            with torch.cuda.stream(run_on):
+                out = d.run()
+            assert d.sync() == [0] * len(part)
+            k0 = jpgs.index(part[0])
+            for k, px in enumerate(d.to_arrays(out)):
+                assert np.array_equal(px, want[k0 + k])
+    finally:
+        d.close()
