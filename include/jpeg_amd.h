@@ -95,6 +95,14 @@ int jpeg_hip_parse_info(const uint8_t *jpg, size_t len, int tolerant, jpeg_hip_f
  * magnitude), out[2] = rounded results that differ.  Both must be zero. */
 int jpeg_hip_selftest_divide(int device, int ties_per_divisor, unsigned seed, unsigned long long out[3]);
 
+/* Self-test of the colour conversion for 8-bit samples (frame_to_ycc, frame.c:154-186, evaluates in binary64; the
+ * encode kernel at precision 8 uses exact binary32 integers and one correctly rounded division per value,
+ * jpeg_amd/csrc/ycc8.inc): both forms on the device for ALL 2^24 (R, G, B).  out[0] = triples tried,
+ * out[1] / out[2] = triples on which the one-pixel / the packed two-pixel form differs from the binary64
+ * expressions in any bit.  Both must be zero.  (The same enumeration against the compiled reference runs on the
+ * host: tests/test_ycc8_cpu.py.) */
+int jpeg_hip_selftest_ycc8(int device, unsigned long long out[3]);
+
 /* ---- batch decoder ------------------------------------------------------------------------
  * One decoder object owns the device workspace for a batch of frames that share geometry
  * (Motion JPEG: every frame is an independent SOI..EOI codestream, decoder.c:603-612).

@@ -41,6 +41,7 @@ EXPORTS = [
     "jpeg_hip_adapt_tables", "jpeg_hip_set_qtable", "jpeg_hip_encoder_set_restart_interval",
     "jpeg_hip_encode_noalloc", "jpeg_hip_encode_noalloc_limit", "jpeg_hip_encode_noalloc_init",
     "jpeg_hip_selftest_divide",
+    "jpeg_hip_selftest_ycc8",
 ]
 
 
@@ -155,6 +156,7 @@ def lib():
         L.jpeg_hip_encode_noalloc.argtypes = [C.c_int, C.POINTER(Params), C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, sz, vp, vp]
         L.jpeg_hip_encode_noalloc_limit.restype = sz
         L.jpeg_hip_selftest_divide.argtypes = [C.c_int, C.c_int, C.c_uint, C.POINTER(C.c_ulonglong)]
+        L.jpeg_hip_selftest_ycc8.argtypes = [C.c_int, C.POINTER(C.c_ulonglong)]
         L.jpeg_hip_set_qtable.argtypes = [vp, C.c_int, C.c_int]
         L.jpeg_hip_set_qtable.restype = None
         L.jpeg_hip_encoder_set_restart_interval.argtypes = [vp, C.c_int]

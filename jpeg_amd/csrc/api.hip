@@ -1864,6 +1864,26 @@ extern "C" int jpeg_hip_selftest_divide(int device, int ties_per_divisor, unsign
 	return e == hipSuccess ? RET_SUCCESS : RET_FAILURE_LOGIC_ERROR;
 }
 
+extern "C" int jpeg_hip_selftest_ycc8(int device, unsigned long long out[3])
+{
+	int err = require_device(device);
+	if (err) {
+		return err;
+	}
+	if (!out) {
+		return RET_FAILURE_LOGIC_ERROR;
+	}
+	unsigned long long *d = nullptr;
+	HIPCHK(hipMalloc((void **)&d, 3 * sizeof *d));
+	hipError_t e = hipMemset(d, 0, 3 * sizeof *d);
+	if (e == hipSuccess && jh_launch_selftest_ycc8(d, nullptr)) {
+		e = hipErrorUnknown;
+	}
+	e = e == hipSuccess ? hipMemcpy(out, d, 3 * sizeof *d, hipMemcpyDeviceToHost) : e;
+	hipFree(d);
+	return e == hipSuccess ? RET_SUCCESS : RET_FAILURE_LOGIC_ERROR;
+}
+
 // ======================================================================================= no-allocation entry point
 
 // jpeg_hip_encode_noalloc(): jpeg_hip_encoder_run() for ONE frame without any device allocation.  No

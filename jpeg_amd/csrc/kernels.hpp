@@ -124,6 +124,7 @@ int jh_launch_encode_pixels(const JhGeom &g, int nframes, const void *in, size_t
                             const JhHuffEnc *codes, struct JhEncState *state, hipStream_t stream);
 
 int jh_launch_selftest_divide(unsigned long long *d_out, int per, unsigned seed, hipStream_t stream);
+int jh_launch_selftest_ycc8(unsigned long long *d_out, hipStream_t stream);
 
 // ---- entropy encoder -------------------------------------------------------------------------------
 

@@ -50,6 +50,14 @@
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 
+// frame_to_ycc at precision 8 in binary32 (see the file: why it equals the reference's binary64 expressions, and
+// the two exhaustive checks), for one pixel and for two at a time (v_pk_mul_f32 / v_pk_fma_f32)
+#include "ycc8.inc"
+#define YCC8_SPLAT1(x) (x)
+#define YCC8_SPLAT2(x) (f2{(x), (x)})
+YCC8_DEFINE(__device__ __forceinline__, ycc8_one, float, YCC8_SPLAT1, __builtin_fmaf)
+YCC8_DEFINE(__device__ __forceinline__, ycc8_two, f2, YCC8_SPLAT2, __builtin_elementwise_fma)
+
 // zig-zag position -> raster index, usable in fully unrolled device code
 __device__ static constexpr int kZig[64] = {
 	 0,  1,  8, 16,  9,  2,  3, 10, 17, 24, 32, 25, 18, 11,  4,  5,
@@ -579,47 +587,152 @@ struct EncPixArgs {
 // tile and (gx0, gy) = the tile's corner + (tx, ty) in the frame.  Offsets from `org` stay below 2^24 * 16
 // and are made with 24-bit multiplies (rowbytes = X * NF * sb < 2^19, ty < 16): the full-width integer
 // multiply runs at a quarter of the rate.
+// whole: every one of the four lies inside the frame and the first sample's address is a multiple of 4
 template <int NF>
-__device__ __forceinline__ void load4(const uint8_t *org, unsigned rowbytes, int tx, int ty, int X, int Y, int sb, int gx0, int gy,
+__device__ __forceinline__ bool load4_whole(const uint8_t *org, unsigned rowbytes, int tx, int ty, int X, int Y, int sb, int gx0, int gy)
+{
+	const uint8_t *p = org + (__umul24((unsigned)ty, rowbytes) + __umul24((unsigned)tx, (unsigned)(NF * sb)));
+	return gx0 + 3 < X && gy < Y && (reinterpret_cast<uintptr_t>(p) & 3) == 0;
+}
+
+template <int NF, int SB, bool WHOLE>
+__device__ __forceinline__ void load4(const uint8_t *org, unsigned rowbytes, int tx, int ty, int X, int Y, int gx0, int gy,
                                       float (&s)[4][NF])
 {
-	if (gx0 + 3 < X && gy < Y) {
-		const uint8_t *p = org + (__umul24((unsigned)ty, rowbytes) + __umul24((unsigned)tx, (unsigned)(NF * sb)));
-		if ((reinterpret_cast<uintptr_t>(p) & 3) == 0) {
-			const uint32_t *pw = reinterpret_cast<const uint32_t *>(p);
-			if (sb == 1) {
-				uint32_t w[NF];
+	if constexpr (WHOLE) {
+		const uint8_t *p = org + (__umul24((unsigned)ty, rowbytes) + __umul24((unsigned)tx, (unsigned)(NF * SB)));
+		const uint32_t *pw = reinterpret_cast<const uint32_t *>(p);
+		if constexpr (SB == 1) {
+			uint32_t w[NF];
 #pragma unroll
-				for (int i = 0; i < NF; ++i) {
-					w[i] = pw[i];
-				}
-#pragma unroll
-				for (int n = 0; n < 4 * NF; ++n) {
-					s[n / NF][n % NF] = (float)((w[n >> 2] >> (8 * (n & 3))) & 0xff);
-				}
-			} else {
-				uint32_t w[2 * NF];
-#pragma unroll
-				for (int i = 0; i < 2 * NF; ++i) {
-					w[i] = pw[i];
-				}
-#pragma unroll
-				for (int n = 0; n < 4 * NF; ++n) {
-					const uint32_t h = (w[n >> 1] >> (16 * (n & 1))) & 0xffff;
-					s[n / NF][n % NF] = (float)(((h & 0xff) << 8) | (h >> 8));   // ntohs (frame.c:321)
-				}
+			for (int i = 0; i < NF; ++i) {
+				w[i] = pw[i];
 			}
-			return;
+#pragma unroll
+			for (int n = 0; n < 4 * NF; ++n) {
+				s[n / NF][n % NF] = (float)((w[n >> 2] >> (8 * (n & 3))) & 0xff);
+			}
+		} else {
+			uint32_t w[2 * NF];
+#pragma unroll
+			for (int i = 0; i < 2 * NF; ++i) {
+				w[i] = pw[i];
+			}
+#pragma unroll
+			for (int n = 0; n < 4 * NF; ++n) {
+				const uint32_t h = (w[n >> 1] >> (16 * (n & 1))) & 0xffff;
+				s[n / NF][n % NF] = (float)(((h & 0xff) << 8) | (h >> 8));   // ntohs (frame.c:321)
+			}
+		}
+	} else {
+		const int sy = min(gy, Y - 1) - (gy - ty);            // inside the tile again
+#pragma unroll
+		for (int i = 0; i < 4; ++i) {
+			const int sx = min(gx0 + i, X - 1) - (gx0 - tx);
+			const uint8_t *p = org + (__umul24((unsigned)sy, rowbytes) + __umul24((unsigned)sx, (unsigned)(NF * SB)));
+#pragma unroll
+			for (int c = 0; c < NF; ++c) {
+				s[i][c] = SB == 1 ? (float)p[c] : (float)((p[2 * c] << 8) | p[2 * c + 1]);
+			}
 		}
 	}
-	const int sy = min(gy, Y - 1) - (gy - ty);            // inside the tile again
+}
+
+// Stage 1 of the encode kernel for one group: SY rows of 4 pixels -> 4 luma values per row and 4 / SX values of each
+// chroma plane, level-shifted, in the tile.  WHOLE: all of the group's samples lie inside the frame and its rows
+// start on dword boundaries (every group of an aligned frame): dword loads, no padding rule, no per-pixel tests.
+template <int NF, int SX, int SY, int SB, bool Y8, bool WHOLE>
+__device__ __forceinline__ void encode_group(float *tile, const TileLayout &L, const uint8_t *org, unsigned rowbytes,
+                                             int rg, int px0, int gx0, int my, int X, int Y, int shift, float shiftf)
+{
+	float ch[2][SY][4];
 #pragma unroll
-	for (int i = 0; i < 4; ++i) {
-		const int sx = min(gx0 + i, X - 1) - (gx0 - tx);
-		const uint8_t *p = org + (__umul24((unsigned)sy, rowbytes) + __umul24((unsigned)sx, (unsigned)(NF * sb)));
+	for (int sy = 0; sy < SY; ++sy) {
+		const int row = rg * SY + sy, gy = my * L.TH + row;
+		float s[4][NF];
+		load4<NF, SB, WHOLE>(org, rowbytes, px0, row, X, Y, gx0, gy, s);
+		float y4[4];
+		if constexpr (NF == 3 && Y8) {
+			// frame_to_ycc (frame.c:168-170) on exact integers and one correctly rounded division each
+			// (ycc8.inc), two pixels per instruction.  Padding pixels keep their raw RGB values (quirk Q7).
+			if (WHOLE) {
+				// the pairs: pixels (0, 2) and (1, 3) where chroma is halved horizontally -- the box sums below then
+				// add whole pairs -- else (0, 1) and (2, 3)
 #pragma unroll
-		for (int c = 0; c < NF; ++c) {
-			s[i][c] = sb == 1 ? (float)p[c] : (float)((p[2 * c] << 8) | p[2 * c + 1]);
+				for (int n = 0; n < 2; ++n) {
+					const int i = SX == 2 ? n : 2 * n, j = SX == 2 ? n + 2 : 2 * n + 1;
+					f2 yl, cb, cr;
+					ycc8_two(f2{s[i][0], s[j][0]}, f2{s[i][1], s[j][1]}, f2{s[i][2], s[j][2]}, &yl, &cb, &cr);
+					s[i][0] = yl.x; s[j][0] = yl.y;
+					s[i][1] = cb.x; s[j][1] = cb.y;
+					s[i][2] = cr.x; s[j][2] = cr.y;
+				}
+			} else {
+#pragma unroll
+				for (int i = 0; i < 4; ++i) {
+					if (gx0 + i < X && gy < Y) {
+						ycc8_one(s[i][0], s[i][1], s[i][2], &s[i][0], &s[i][1], &s[i][2]);
+					}
+				}
+			}
+		}
+#pragma unroll
+		for (int i = 0; i < 4; ++i) {
+			if constexpr (NF == 3) {
+				if constexpr (!Y8) {
+					if (WHOLE || (gx0 + i < X && gy < Y)) {
+						// frame_to_ycc (frame.c:168-170): double arithmetic, left to right, rounded to
+						// float.  Padding pixels keep their raw RGB values (loops stop at X, Y: quirk Q7).
+						const float R = s[i][0], G_ = s[i][1], B_ = s[i][2];
+						// The products with 0.5 are exact (a power of two), so `t + 0.5 * B` and `0.5 * R - t` round
+						// once either way: written as fused operations they cost one instruction instead of two
+						// and give the same binary64 value.  Every other product rounds on its own, as in C.
+						const double Rd = R, Gd = G_, Bd = B_;
+						const float Yl = 0.299 * Rd + 0.587 * Gd + 0.114 * Bd;
+						const float Cb = __builtin_fma(0.5, Bd, - 0.1687 * Rd - 0.3313 * Gd) + shift;
+						const float Cr = __builtin_fma(0.5, Rd, -(0.4187 * Gd)) - 0.0813 * Bd + shift;
+						s[i][0] = Yl;
+						s[i][1] = Cb;
+						s[i][2] = Cr;
+					}
+				}
+				ch[0][sy][i] = s[i][1];
+				ch[1][sy][i] = s[i][2];
+			}
+			// luma: step 1 x 1: px = 0.f + s; px /= 1 (frame.c:114-123); then the level shift
+			// of forward_dct (imgproc.c:220-222).  s is a sample or a luma value, never -0: 0.f + s == s
+			y4[i] = s[i][0] - shiftf;
+		}
+		*reinterpret_cast<float4 *>(tile + L.base[0] + (int)__umul24((unsigned)row, (unsigned)L.pitch[0]) + px0) =
+			make_float4(y4[0], y4[1], y4[2], y4[3]);
+	}
+	if constexpr (NF == 3) {
+#pragma unroll
+		for (int c = 0; c < 2; ++c) {
+			float o[4 / SX];
+#pragma unroll
+			for (int ox = 0; ox < 4 / SX; ++ox) {
+				// transform_frame_to_components (frame.c:114-123): px = 0.f; += (yy outer, xx inner); /= area.
+				// The first term is a sample or `... + shift` in binary64, never -0: 0.f + it == it
+				float px = ch[c][0][ox * SX];
+#pragma unroll
+				for (int yy = 0; yy < SY; ++yy) {
+#pragma unroll
+					for (int xx = 0; xx < SX; ++xx) {
+						if (yy + xx) {
+							px += ch[c][yy][ox * SX + xx];
+						}
+					}
+				}
+				px /= (float)(SY * SX);
+				o[ox] = px - shiftf;
+			}
+			float *dst = tile + L.base[c + 1] + (int)__umul24((unsigned)rg, (unsigned)L.pitch[c + 1]) + px0 / SX;
+			if constexpr (SX == 1) {
+				*reinterpret_cast<float4 *>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+			} else {
+				*reinterpret_cast<float2 *>(dst) = make_float2(o[0], o[1]);
+			}
 		}
 	}
 }
@@ -646,17 +759,23 @@ __device__ __forceinline__ unsigned nz_octet(const int4 v)
 //   pbits  AC bits of the two halves of a block
 //   actab  size + category of every AC symbol per table id (0: never looked up, 0x4000: no code)
 //   acfix  sizes of EOB / ZRL per table id
+//   runtab what a coefficient of category c behind a zero run of r = 0 ... 63 costs: actab[r & 15][c] plus
+//          (r >> 4) times the size of ZRL -- one look-up per nonzero coefficient, nothing to mask or multiply
 struct Stage5 {
 	unsigned long long nzm[128];
 	unsigned pbits[2][128];
 	uint16_t actab[2][256];
 	uint16_t acfix[2][2];
+	uint16_t pad[4];
+	__attribute__((aligned(16))) uint16_t runtab[2][64][16];
 };
 #define STAGE5_OFF (TILE_BLOCKS * LINE_I16 * 2)             // bytes: behind the lines of a full tile
 
 // NF = 1: one plane, no sub-sampling.  NF = 3: luma at full resolution, both chroma planes
 // down-sampled SX x SY (what read_image() sets up: luma H x V, chroma 1 x 1; encoder.c:109-146).
-template <int NF, int SX, int SY>
+// Y8: 8-bit samples at precision 8 -- frame_to_ycc without binary64 (ycc8.inc).
+// SB: bytes per sample
+template <int NF, int SX, int SY, int SB, bool Y8>
 __global__ __launch_bounds__(256) void k_encode_pixels(const EncPixArgs a)
 {
 	extern __shared__ __align__(16) float tile[];
@@ -677,10 +796,10 @@ __global__ __launch_bounds__(256) void k_encode_pixels(const EncPixArgs a)
 	const int X = g.X, Y = g.Y;
 	const int shift = 1 << (g.P - 1);
 	const float shiftf = (float)shift;
-	const unsigned rowbytes = (unsigned)X * (unsigned)(NF * g.sample_bytes);
+	const unsigned rowbytes = (unsigned)X * (unsigned)(NF * SB);
 	// the tile's first sample
 	const uint8_t *org = a.in + (size_t)f * a.frame_stride + (size_t)(my * L.TH) * rowbytes +
-		(size_t)(mx0 * 8 * g.max_H) * (size_t)(NF * g.sample_bytes);
+		(size_t)(mx0 * 8 * g.max_H) * (size_t)(NF * SB);
 
 	for (int i = tid; i < 2 * 64; i += 256) {
 		const float d = (float)a.quant[f].q[i >> 6][i & 63];
@@ -706,69 +825,15 @@ __global__ __launch_bounds__(256) void k_encode_pixels(const EncPixArgs a)
 				continue;
 			}
 			const int gx0 = mx0 * 8 * g.max_H + px0;
-			float ch[2][SY][4];
+			bool whole = true;
 #pragma unroll
 			for (int sy = 0; sy < SY; ++sy) {
-				const int row = rg * SY + sy, gy = my * L.TH + row;
-				float s[4][NF];
-				load4<NF>(org, rowbytes, px0, row, X, Y, g.sample_bytes, gx0, gy, s);
-				float y4[4];
-#pragma unroll
-				for (int i = 0; i < 4; ++i) {
-					if constexpr (NF == 3) {
-						if (gx0 + i < X && gy < Y) {
-							// frame_to_ycc (frame.c:168-170): double arithmetic, left to right, rounded to
-							// float.  Padding pixels keep their raw RGB values (loops stop at X, Y: quirk Q7).
-							const float R = s[i][0], G_ = s[i][1], B_ = s[i][2];
-							// The products with 0.5 are exact (a power of two), so `t + 0.5 * B` and `0.5 * R - t` round
-							// once either way: written as fused operations they cost one instruction instead of two
-							// and give the same binary64 value.  Every other product rounds on its own, as in C.
-							const double Rd = R, Gd = G_, Bd = B_;
-							const float Yl = 0.299 * Rd + 0.587 * Gd + 0.114 * Bd;
-							const float Cb = __builtin_fma(0.5, Bd, - 0.1687 * Rd - 0.3313 * Gd) + shift;
-							const float Cr = __builtin_fma(0.5, Rd, -(0.4187 * Gd)) - 0.0813 * Bd + shift;
-							s[i][0] = Yl;
-							s[i][1] = Cb;
-							s[i][2] = Cr;
-						}
-						ch[0][sy][i] = s[i][1];
-						ch[1][sy][i] = s[i][2];
-					}
-					// luma: step 1 x 1: px = 0.f + s; px /= 1 (frame.c:114-123); then the level shift
-					// of forward_dct (imgproc.c:220-222).  s is a sample or a luma value, never -0: 0.f + s == s
-					y4[i] = s[i][0] - shiftf;
-				}
-				*reinterpret_cast<float4 *>(tile + L.base[0] + (int)__umul24((unsigned)row, (unsigned)L.pitch[0]) + px0) =
-					make_float4(y4[0], y4[1], y4[2], y4[3]);
+				whole = whole && load4_whole<NF>(org, rowbytes, px0, rg * SY + sy, X, Y, SB, gx0, my * L.TH + rg * SY + sy);
 			}
-			if constexpr (NF == 3) {
-#pragma unroll
-				for (int c = 0; c < 2; ++c) {
-					float o[4 / SX];
-#pragma unroll
-					for (int ox = 0; ox < 4 / SX; ++ox) {
-						// transform_frame_to_components (frame.c:114-123): px = 0.f; += (yy outer, xx inner); /= area.
-						// The first term is a sample or `... + shift` in binary64, never -0: 0.f + it == it
-						float px = ch[c][0][ox * SX];
-#pragma unroll
-						for (int yy = 0; yy < SY; ++yy) {
-#pragma unroll
-							for (int xx = 0; xx < SX; ++xx) {
-								if (yy + xx) {
-									px += ch[c][yy][ox * SX + xx];
-								}
-							}
-						}
-						px /= (float)(SY * SX);
-						o[ox] = px - shiftf;
-					}
-					float *dst = tile + L.base[c + 1] + (int)__umul24((unsigned)rg, (unsigned)L.pitch[c + 1]) + px0 / SX;
-					if constexpr (SX == 1) {
-						*reinterpret_cast<float4 *>(dst) = make_float4(o[0], o[1], o[2], o[3]);
-					} else {
-						*reinterpret_cast<float2 *>(dst) = make_float2(o[0], o[1]);
-					}
-				}
+			if (whole) {
+				encode_group<NF, SX, SY, SB, Y8, true>(tile, L, org, rowbytes, rg, px0, gx0, my, X, Y, shift, shiftf);
+			} else {
+				encode_group<NF, SX, SY, SB, Y8, false>(tile, L, org, rowbytes, rg, px0, gx0, my, X, Y, shift, shiftf);
 			}
 		}
 	}
@@ -887,6 +952,9 @@ __global__ __launch_bounds__(256) void k_encode_pixels(const EncPixArgs a)
 	if (!a.codes) {
 		return;
 	}
+#ifdef X_SKIP5
+	return;
+#endif
 	for (int i = tid; i < 2 * 256; i += 256) {
 		const int th = i >> 8, sym = i & 255, cat = sym & 15;
 		const unsigned size = a.codes[(size_t)f * 4 + 2 + th].code[sym] & 0xffu;
@@ -897,6 +965,16 @@ __global__ __launch_bounds__(256) void k_encode_pixels(const EncPixArgs a)
 		if (sym == 0xf0) {
 			s5.acfix[th][1] = (uint16_t)(size ? size : 0x4000u);
 		}
+	}
+	__syncthreads();
+	{
+		// runtab from actab: thread = (table, run, eight categories), one 16-byte read, one 16-byte write.  A flagged
+		// entry (0x4000) stays flagged: at most 3 * 16 is added.
+		const int th = tid >> 7, run = (tid >> 1) & 63, half = tid & 1;
+		const unsigned z = (unsigned)(run >> 4) * s5.acfix[th][1], zz = z | (z << 16);
+		uint4 v = *reinterpret_cast<const uint4 *>(&s5.actab[th][((run & 15) << 4) + half * 8]);
+		v.x += zz; v.y += zz; v.z += zz; v.w += zz;        // no carry between the halves: every entry < 0x8000
+		*reinterpret_cast<uint4 *>(&s5.runtab[th][run][half * 8]) = v;
 	}
 	__syncthreads();
 
@@ -912,8 +990,8 @@ __global__ __launch_bounds__(256) void k_encode_pixels(const EncPixArgs a)
 			const int mcu = B == 1 ? b : (int)(__umul24((unsigned)b, L.b_magic16) >> 16);
 			const int k = b - (int)__umul24((unsigned)mcu, (unsigned)B);
 			const int ta = kt.kta[k];
-			const uint16_t *T = s5.actab[ta];
-			const unsigned eob = s5.acfix[ta][0], zrl = s5.acfix[ta][1];
+			const uint16_t *T = &s5.runtab[ta][0][0];
+			const unsigned eob = s5.acfix[ta][0];
 			const int16_t *line = reinterpret_cast<const int16_t *>(tile) + b * LINE_I16 + h * 32;
 			const unsigned long long map = s5.nzm[b];
 			const unsigned lo = (unsigned)map & ~1u, hi = (unsigned)(map >> 32);
@@ -931,8 +1009,8 @@ __global__ __launch_bounds__(256) void k_encode_pixels(const EncPixArgs a)
 				const int run = z - prev - 1;
 				prev = z;
 				const int cat = __builtin_amdgcn_frexp_expf((float)c);  // bits of |c| (encode_cat, coeffs.c:56-74)
-				bits += tprev + __umul24((unsigned)(run >> 4), zrl);    // 24-bit: the 32-bit multiply runs at a quarter of the rate
-				tprev = T[((run & 15) << 4) | cat];
+				bits += tprev;
+				tprev = T[(run << 4) + cat];
 				z = zn;
 				c = cn;
 			}
@@ -973,28 +1051,44 @@ int jh_launch_encode_pixels(const JhGeom &g, int nframes, const void *in, size_t
 	if (a.codes && lds < STAGE5_OFF + sizeof(Stage5)) {
 		lds = STAGE5_OFF + sizeof(Stage5);                 // small tiles: room for stage 5 behind the lines
 	}
+	if (g.sample_bytes != 1 && g.sample_bytes != 2) {
+		return -1;
+	}
+	// 0: 16-bit samples, 1: 8-bit samples, 2: 8-bit samples at precision 8 (frame_to_ycc in binary32: ycc8.inc)
+	const int mode = g.sample_bytes == 2 ? 0 : (g.P == 8 && g.Nf == 3 ? 2 : 1);
+#define JH_ENC_LAUNCH(NF, SX, SY)                                                                              \
+	do {                                                                                                       \
+		if (mode == 0) {                                                                                       \
+			hipLaunchKernelGGL((k_encode_pixels<NF, SX, SY, 2, false>), grid, dim3(256), lds, stream, a);      \
+		} else if (mode == 1) {                                                                                \
+			hipLaunchKernelGGL((k_encode_pixels<NF, SX, SY, 1, false>), grid, dim3(256), lds, stream, a);      \
+		} else {                                                                                               \
+			hipLaunchKernelGGL((k_encode_pixels<NF, SX, SY, 1, NF == 3>), grid, dim3(256), lds, stream, a);    \
+		}                                                                                                      \
+	} while (0)
 	if (g.Nf == 1) {
-		hipLaunchKernelGGL((k_encode_pixels<1, 1, 1>), grid, dim3(256), lds, stream, a);
+		JH_ENC_LAUNCH(1, 1, 1);
 	} else if (g.Nf == 3 && g.step_x[0] == 1 && g.step_y[0] == 1 && g.step_x[1] == g.max_H && g.step_y[1] == g.max_V &&
 	           g.step_x[2] == g.max_H && g.step_y[2] == g.max_V && g.max_H <= 2 && g.max_V <= 2) {
 		const int code = g.max_H * 10 + g.max_V;
 		switch (code) {
 		case 11:
-			hipLaunchKernelGGL((k_encode_pixels<3, 1, 1>), grid, dim3(256), lds, stream, a);
+			JH_ENC_LAUNCH(3, 1, 1);
 			break;
 		case 21:
-			hipLaunchKernelGGL((k_encode_pixels<3, 2, 1>), grid, dim3(256), lds, stream, a);
+			JH_ENC_LAUNCH(3, 2, 1);
 			break;
 		case 12:
-			hipLaunchKernelGGL((k_encode_pixels<3, 1, 2>), grid, dim3(256), lds, stream, a);
+			JH_ENC_LAUNCH(3, 1, 2);
 			break;
 		default:
-			hipLaunchKernelGGL((k_encode_pixels<3, 2, 2>), grid, dim3(256), lds, stream, a);
+			JH_ENC_LAUNCH(3, 2, 2);
 			break;
 		}
 	} else {
 		return -1;   // jpeg_hip_encoder_configure() admits nothing else (encoder.c:123-124)
 	}
+#undef JH_ENC_LAUNCH
 	return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -1045,6 +1139,46 @@ __global__ __launch_bounds__(256) void k_selftest_divide(unsigned long long *out
 	atomicAdd(&out[0], cases);
 	atomicAdd(&out[1], badq);
 	atomicAdd(&out[2], badr);
+}
+
+// ycc8_one() / ycc8_two() against the binary64 expressions of frame_to_ycc (frame.c:168-170) as the compiler
+// evaluates them (unfused: -ffp-contract=off), for all 2^24 (R, G, B): thread = (R, G), loop over B in pairs.
+// out[0] = triples, out[1] = triples where the one-pixel form differs in any of the three bit patterns,
+// out[2] = the same for the two-pixel form
+__global__ __launch_bounds__(256) void k_selftest_ycc8(unsigned long long *out)
+{
+	const int rg = blockIdx.x * 256 + threadIdx.x;
+	const float R = (float)(rg >> 8), G = (float)(rg & 255);
+	const int shift = 128;
+	unsigned long long bad1 = 0, bad2 = 0;
+	for (int b = 0; b < 256; b += 2) {
+		float w[2][3];
+		for (int i = 0; i < 2; ++i) {
+			const float B = (float)(b + i);
+			w[i][0] = 0.299 * R + 0.587 * G + 0.114 * B;
+			w[i][1] = - 0.1687 * R - 0.3313 * G + 0.5 * B + shift;
+			w[i][2] = 0.5 * R - 0.4187 * G - 0.0813 * B + shift;
+			float y, cb, cr;
+			ycc8_one(R, G, B, &y, &cb, &cr);
+			bad1 += __float_as_uint(y) != __float_as_uint(w[i][0]) || __float_as_uint(cb) != __float_as_uint(w[i][1]) ||
+			        __float_as_uint(cr) != __float_as_uint(w[i][2]);
+		}
+		f2 y, cb, cr;
+		ycc8_two(f2{R, R}, f2{G, G}, f2{(float)b, (float)(b + 1)}, &y, &cb, &cr);
+		bad2 += __float_as_uint(y.x) != __float_as_uint(w[0][0]) || __float_as_uint(cb.x) != __float_as_uint(w[0][1]) ||
+		        __float_as_uint(cr.x) != __float_as_uint(w[0][2]);
+		bad2 += __float_as_uint(y.y) != __float_as_uint(w[1][0]) || __float_as_uint(cb.y) != __float_as_uint(w[1][1]) ||
+		        __float_as_uint(cr.y) != __float_as_uint(w[1][2]);
+	}
+	atomicAdd(&out[0], 256ull);
+	atomicAdd(&out[1], bad1);
+	atomicAdd(&out[2], bad2);
+}
+
+int jh_launch_selftest_ycc8(unsigned long long *d_out, hipStream_t stream)
+{
+	hipLaunchKernelGGL(k_selftest_ycc8, dim3(256), dim3(256), 0, stream, d_out);
+	return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
 int jh_launch_selftest_divide(unsigned long long *d_out, int per, unsigned seed, hipStream_t stream)

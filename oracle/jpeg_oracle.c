@@ -1294,6 +1294,22 @@ static void put_dht(sink *s, int Tc, int Th, const uint8_t L[16], const uint8_t 
 	}
 }
 
+/* frame.c:162-176, the body of frame_to_ycc's loops: n interleaved (R, G, B) float triples in place.
+ * Binary64 arithmetic, left to right, rounded to binary32 on assignment. */
+void orc_frame_to_ycc(float *px, size_t n, int P)
+{
+	int shift = 1 << (P - 1);
+	for (size_t i = 0; i < n; ++i, px += 3) {
+		float R = px[0], G = px[1], B = px[2];
+		float Yl = 0.299 * R + 0.587 * G + 0.114 * B;
+		float Cb = - 0.1687 * R - 0.3313 * G + 0.5 * B + shift;
+		float Cr = 0.5 * R - 0.4187 * G - 0.0813 * B + shift;
+		px[0] = Yl;
+		px[1] = Cb;
+		px[2] = Cr;
+	}
+}
+
 int orc_encode(const uint8_t *body, int X, int Y, int Nf, int P, int H, int V, int q,
                int optimize, int restart_interval,
                orc_image **img_out, uint8_t **jpg, size_t *jpg_len)
@@ -1378,18 +1394,8 @@ int orc_encode(const uint8_t *body, int X, int Y, int Nf, int P, int H, int V, i
 
 	/* frame.c:154-186 frame_to_ycc: only x < X, y < Y (padding keeps raw RGB, quirk Q7) */
 	if (Nf == 3) {
-		int shift = 1 << (P - 1);
 		for (size_t y = 0; y < (size_t)Y; ++y) {
-			for (size_t x = 0; x < (size_t)X; ++x) {
-				float *px = &frame[y * sx * 3 + x * 3];
-				float R = px[0], G = px[1], B = px[2];
-				float Yl = 0.299 * R + 0.587 * G + 0.114 * B;
-				float Cb = - 0.1687 * R - 0.3313 * G + 0.5 * B + shift;
-				float Cr = 0.5 * R - 0.4187 * G - 0.0813 * B + shift;
-				px[0] = Yl;
-				px[1] = Cb;
-				px[2] = Cr;
-			}
+			orc_frame_to_ycc(&frame[y * sx * 3], (size_t)X, P);
 		}
 	}
 

@@ -95,6 +95,7 @@ int  orc_encode_cat(int32_t c);                           /* coeffs.c:56-74 */
 int  orc_encode_extra(int32_t c, int cat);                /* coeffs.c:76-83 */
 int32_t orc_decode_coeff(int cat, int extra);             /* coeffs.c:33-48 */
 void orc_set_qtable(uint16_t Q[64], int chroma, int q);   /* encoder.c:38-65 */
+void orc_frame_to_ycc(float *px, size_t n, int P);        /* frame.c:162-176: n (R, G, B) triples in place */
 /* Annex C code generation (huffman.c:45-178): sizes/codes per symbol (EHUFSI/EHUFCO) */
 int  orc_make_codes(const uint8_t L[16], const uint8_t V[256], uint8_t ehufsi[256], uint16_t ehufco[256]);
 /* Annex K.2 optimiser (huffman.c:330-537): freq[257] (freq[256] must be 1) -> L, V */

@@ -127,3 +127,20 @@ void ref_tap_comp_info(int k, int *id, int *H, int *V, int *Tq, size_t *bx, size
 const int32_t *ref_tap_coef(int k) { return tap.coef[k]; }
 
 const uint16_t *ref_tap_qtable(int t) { return tap.Q[t]; }
+
+/* The reference's own frame_to_ycc() (frame.c:154-186) on a caller-made interleaved float frame of
+ * Y rows of X (R, G, B) triples (no padding: size_x = X), in place. */
+int ref_frame_to_ycc(float *data, int X, int Y, int precision)
+{
+	struct frame frame;
+
+	memset(&frame, 0, sizeof frame);
+	frame.components = 3;
+	frame.X = (uint16_t)X;
+	frame.Y = (uint16_t)Y;
+	frame.size_x = (size_t)X;
+	frame.size_y = (size_t)Y;
+	frame.precision = (uint8_t)precision;
+	frame.data = data;
+	return frame_to_ycc(&frame);
+}

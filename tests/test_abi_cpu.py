@@ -20,7 +20,7 @@ def built_lib():
 
 def test_header_symbols_are_exported(built_lib):
     hdr = open(os.path.join(ROOT, "include", "jpeg_amd.h")).read()
-    declared = sorted(set(re.findall(r"\b(jpeg_hip_[a-z_]+)\s*\(", hdr)))
+    declared = sorted(set(re.findall(r"\b(jpeg_hip_[a-z0-9_]+)\s*\(", hdr)))
     assert len(declared) >= 25
     L = C.CDLL(built_lib.LIB_PATH)
     for name in declared:

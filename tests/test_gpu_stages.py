@@ -209,3 +209,13 @@ def test_quantiser_division_against_the_compilers_own(hip):
         assert hip.lib().jpeg_hip_selftest_divide(0, per, seed, out) == 0
         cases, badq, badr = (int(v) for v in out)
         assert cases > 50_000_000 and badq == 0 and badr == 0, (cases, badq, badr)
+
+
+def test_colour_conversion_without_binary64_on_all_rgb_triples(hip):
+    """frame_to_ycc (frame.c:154-186) evaluates in binary64; at precision 8 the encode kernel uses exact binary32
+    integers and one correctly rounded division per value (jpeg_amd/csrc/ycc8.inc).  jpeg_hip_selftest_ycc8 runs
+    both forms of it (one pixel, two pixels packed) against the binary64 expressions on the device for all 2^24
+    (R, G, B); tests/test_ycc8_cpu.py runs the same text against the compiled reference on the host."""
+    out = (C.c_ulonglong * 3)()
+    assert hip.lib().jpeg_hip_selftest_ycc8(0, out) == 0
+    assert [int(v) for v in out] == [1 << 24, 0, 0], [int(v) for v in out]
