@@ -113,20 +113,63 @@ def kernel_times(obj, run, torch, reps=5):
     return {k: v / reps for k, v in acc.items()}
 
 
+def csrc_sha16():
+    """what the profiles are tagged with: a hash of the kernel sources (the GPU box has no .git to ask)"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for path in sorted(glob.glob(os.path.join(ROOT, "jpeg_amd", "csrc", "*"))):
+        if path.endswith((".hip", ".hpp", ".inc", ".cpp")):
+            h.update(os.path.basename(path).encode() + b"\0" + open(path, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def newest_profile(suffix):
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_" + suffix)))
+    if not files:
+        return None, None
+    with open(files[-1]) as f:
+        return json.load(f), os.path.basename(files[-1])
+
+
+def profile_source(d, fname):
+    """which committed profile a counter figure comes from, and whether the kernels have changed since (loudly)"""
+    src = {"file": "profiles/" + fname, "head": d.get("head"), "csrc_sha16": d.get("csrc_sha16")}
+    src["matches_this_tree"] = d.get("csrc_sha16") == csrc_sha16()
+    if not src["matches_this_tree"]:
+        sys.stderr.write("bench.py: WARNING: %s was collected on other kernel sources (csrc_sha16 %s, this tree %s): the "
+                         "counter figures of the roofline block are STALE -- re-run tools/profile.sh\n"
+                         % (src["file"], d.get("csrc_sha16"), csrc_sha16()))
+    return src
+
+
 def pmc_traffic(kernel, frames):
     """HBM bytes per launch of `kernel` from the newest committed rocprofv3 --pmc summary
     (profiles/rNN_*_pmc_traffic.json: FETCH_SIZE / WRITE_SIZE passes of this same command, gfx950
-    correction applied), scaled to this run's frames per launch.  None if there is no such file."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
-    if not files:
-        return None
-    with open(files[-1]) as f:
-        d = json.load(f)
-    k = d.get("kernels", {}).get(kernel)
+    correction applied), scaled to this run's frames per launch, and where it came from.  (None, None) if
+    there is no such file."""
+    d, fname = newest_profile("pmc_traffic.json")
+    k = d.get("kernels", {}).get(kernel) if d else None
     if not k:
+        return None, None
+    return int(k["hbm_bytes"] * frames / d["frames_per_launch"]), profile_source(d, fname)
+
+
+def pmc_valu(kernel, frames, kernel_ms, clock_ghz=2.4, simds=1024):
+    """The ceiling a VALU-bound kernel runs against: vector instructions per wave from the newest committed SQ
+    counter passes, and the share of the launch's SIMD cycles in which the vector unit was busy with them
+    (SQ_ACTIVE_INST_VALU counts units of four cycles, one per ordinary instruction; 256 CUs x 4 SIMDs at the peak
+    engine clock), against this run's live kernel time."""
+    d, fname = newest_profile("pmc_sq.json")
+    k = d.get("kernels", {}).get(kernel) if d else None
+    if not k or "SQ_ACTIVE_INST_VALU" not in k["counters"]:
         return None
-    return int(k["hbm_bytes"] * frames / d["frames_per_launch"])
+    c = k["counters"]
+    scale = frames / d["frames_per_launch"]
+    busy = 4.0 * c["SQ_ACTIVE_INST_VALU"] * scale / (simds * clock_ghz * 1e9 * kernel_ms * 1e-3)
+    return {"insts_per_wave": k["derived"].get("valu_insts_per_wave"), "waves_per_launch": int(c.get("SQ_WAVES", 0) * scale),
+            "busy_frac": round(busy, 4), "clock_ghz": clock_ghz, "source": profile_source(d, fname)}
 
 
 def measure_workload(torch, binding, synth, name, nframes, device, steps, restart_interval=0):
@@ -185,6 +228,7 @@ def mjpeg_stream(torch, binding, synth, mjpeg, dev, rank, world, dist, batch, di
     stream = [jpgs[i % distinct] for i in range(STREAM_FRAMES)]
     lo, hi = mjpeg.shard(STREAM_FRAMES, rank, world)
     mine = stream[lo:hi]
+    shard_bytes = sum(len(j) for j in mine)
 
     # expected totals of the WHOLE stream as one process would see them: the stream repeats `distinct` frames
     d = binding.Decoder(dev)
@@ -215,7 +259,12 @@ def mjpeg_stream(torch, binding, synth, mjpeg, dev, rank, world, dist, batch, di
         t_all = time.perf_counter() - t0
         if dist is not None:
             t_all = reduce_max(torch, dist, t_all)
-        return n, acc, t_rank, t_all
+        # EVERY pass is checked, the reported one included: frames, bytes and the checksum of checksums, gathered
+        # over the ranks, against what one process decoding the whole stream sees (outside the timed region)
+        got = [int(v) for v in torch.cat(acc).tolist()]
+        tot = mjpeg.gather_stats({"frames": n, "bytes": shard_bytes, "checksum": mjpeg.combine_checksums(got)}, dist)
+        assert tot["frames"] == STREAM_FRAMES and tot["bytes"] == expect_bytes and tot["checksum"] == expect_cs, tot
+        return n, tot, t_rank, t_all
 
     # (a) the rank's part of the file in ONE page-locked buffer (what an I/O layer that owns its buffers delivers:
     # every byte is read from DRAM by the DMA engine, no staging copy); (b) frames as pageable Python bytes objects
@@ -226,14 +275,11 @@ def mjpeg_stream(torch, binding, synth, mjpeg, dev, rank, world, dist, batch, di
     runs = {"pinned": [], "pageable": []}
     for kind, src in (("pinned", pinned), ("pageable", mine)):
         for attempt in range(3):
-            n, acc, t_rank, t_all = timed_pass(src)
+            n, tot, t_rank, t_all = timed_pass(src)
             runs[kind].append((t_rank, t_all))
     pinned.buf.close()
     best = min(runs["pinned"][1:], key=lambda r: r[1])
-    got = [int(v) for v in torch.cat(acc).tolist()]
-    local = {"frames": n, "bytes": sum(len(j) for j in mine), "checksum": mjpeg.combine_checksums(got)}
-    tot = mjpeg.gather_stats(local, dist)
-    ok = tot["frames"] == STREAM_FRAMES and tot["bytes"] == expect_bytes and tot["checksum"] == expect_cs
+    ok = True                                              # every pass asserted its totals above
     rates = [n / best[0]]
     if dist is not None:
         tt = torch.tensor([n / best[0]], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
@@ -249,6 +295,75 @@ def mjpeg_stream(torch, binding, synth, mjpeg, dev, rank, world, dist, batch, di
         "per_rank_frames_per_s": [round(r, 1) for r in rates],
         "gathered": {"frames": tot["frames"], "bytes": tot["bytes"], "checksum": tot["checksum"]},
         "matches_single_process_totals": ok,
+    }
+
+
+def mjpeg_encode_stream(torch, binding, synth, mjpeg, dev, rank, world, dist, batch, distinct=32):
+    """The encode direction of BASELINE configs[4]: 10 000 frames of 1080p 4:2:2 q85, sharded like the decode
+    stream.  Host-inclusive on the OUTPUT side: samples resident in HBM (where a renderer, a capture DMA or the
+    decoder leaves them; uploading 6.2 MB per frame would cap the stream at the link's 8.8 k frames/s) -> finished
+    codestreams packed back to back in page-locked host memory, ready to be written out as a Motion JPEG file."""
+    X, Y, nc, P, H, V, q, opt, safe, seed = synth.CONFIGS["c5_1080p_422_q85"]
+    enc, samples, jpgs, cfg = make_batch(torch, binding, synth, "c5_1080p_422_q85", distinct, dev)
+    enc.close()
+    lo, hi = mjpeg.shard(STREAM_FRAMES, rank, world)
+    big = torch.cat([samples] * ((batch + distinct - 1) // distinct))[:batch].contiguous()    # one batch, frame i = image i % distinct
+    del samples
+    assert batch % distinct == 0 or world * batch >= STREAM_FRAMES
+    want_len = [len(jpgs[i % distinct]) for i in range(batch)]
+    counts = [min(batch, hi - lo - k) for k in range(0, hi - lo, batch)]
+    expect_bytes = 0                                       # of the whole stream: every rank's batches start at image 0
+    for r in range(world):
+        rlo, rhi = mjpeg.shard(STREAM_FRAMES, r, world)
+        expect_bytes += sum(sum(want_len[:min(batch, rhi - rlo - k)]) for k in range(0, rhi - rlo, batch))
+
+    def batches():
+        for n in counts:
+            yield big[:n]
+
+    def one_pass(check_bytes):
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        t0 = time.perf_counter()
+        frames = nbytes = 0
+        lens_ok = True
+        for view, off, st in mjpeg.encode_stream(batches(), X, Y, nc, P=P, H=H, V=V, q=q, optimize=opt, device=dev):
+            n = len(st)
+            lens_ok = lens_ok and not any(st) and [off[f + 1] - off[f] for f in range(n)] == want_len[:n]
+            if check_bytes:                                # the untimed pass: every byte of every frame
+                for f in range(n):
+                    assert bytes(view[off[f]:off[f + 1]]) == jpgs[f % distinct], "frame %d of a batch differs" % f
+            frames += n
+            nbytes += off[-1]
+        t_rank = time.perf_counter() - t0
+        if dist is not None:
+            dist.barrier()
+        t_all = time.perf_counter() - t0
+        if dist is not None:
+            t_all = reduce_max(torch, dist, t_all)
+        assert lens_ok
+        tot = mjpeg.gather_stats({"frames": frames, "bytes": nbytes, "checksum": 0}, dist)
+        assert tot["frames"] == STREAM_FRAMES and tot["bytes"] == expect_bytes, tot
+        return frames, tot, t_rank, t_all
+
+    one_pass(True)                                         # creates the workspaces; compares every byte with the codestreams of
+                                                           # the encoder object (which tests/ pin to the oracle)
+    runs = [one_pass(False) for _ in range(3)]
+    best = min(runs, key=lambda r: r[3])
+    rates = [best[0] / best[2]]
+    if dist is not None:
+        tt = torch.tensor([rates[0]], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        allv = [torch.zeros_like(tt) for _ in range(world)]
+        dist.all_gather(allv, tt)
+        rates = [float(v.item()) for v in allv]
+    return {
+        "frames": best[1]["frames"], "distinct_frames": distinct, "batch": batch, "bytes_per_frame": best[1]["bytes"] // STREAM_FRAMES,
+        "host_inclusive_encode_frames_per_s": round(STREAM_FRAMES / best[3], 1),
+        "output": "each batch's codestreams back to back in page-locked host memory (jpeg_hip_encoder_run_stream); samples resident in HBM",
+        "passes_frames_per_s": [round(STREAM_FRAMES / r[3], 1) for r in runs],
+        "per_rank_frames_per_s": [round(r, 1) for r in rates],
+        "verified": "status, frame count and every frame's length in every pass; every byte in an untimed pass",
     }
 
 
@@ -433,7 +548,7 @@ def main():
         "value": round(value, 1), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(t / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "dtype_detail": "pixel kernels: binary32 DCT / quantisation and binary64 colour maths, bit-exact with the reference; "
+        "dtype_detail": "pixel kernels: binary32 DCT / quantisation / RGB->YCbCr (8-bit), binary64 colour maths elsewhere, bit-exact with the reference; "
                         "entropy kernels: u8 / int16 / u32 integer work",
         "config": {"workload": "metric_4k_420_q90: 3840x2160 8-bit 4:2:0 q90, default Huffman tables, no restart markers",
                    "frames_per_gpu_per_step": F, "distinct_frames": min(F, HOST_SYNTH) if HOST_SYNTH else F,
@@ -465,8 +580,10 @@ def main():
         jpg_bytes = sum(len(j) for j in jpgs)
         alg_bytes = F * pix * cfg["nc"] + jpg_bytes        # W*H*Nc*s + B_jpeg per frame
         achieved = alg_bytes / (allk[dom] * 1e-3) / 1e9
+        traffic, traffic_src = pmc_traffic(dom, F)
         res["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                           "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(dom, F),
+                           "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                           "traffic_source": traffic_src, "valu": pmc_valu(dom, F, allk[dom]),
                            "alg_bytes_per_launch": alg_bytes, "kernel_ms": round(allk[dom], 4)}
         res["kernel_ms"] = {k: round(v, 4) for k, v in sorted(allk.items(), key=lambda kv: -kv[1])}
         res["pipeline_hbm_frac"] = {"decode": round(alg_bytes / (t_d / args.steps) / 1e9 / HBM_PEAK_GBS, 5),
@@ -488,18 +605,12 @@ def main():
                 w["encode_frames_per_s"] = round(w["encode_mpix_s"] * 1e6 / (1920 * 1080), 1)
             res["workloads"][name + ("_ri%d" % ri if ri else "")] = w
 
-    if not args.no_mjpeg:
-        ms = mjpeg_stream(torch, binding, synth, mjpeg, dev, rank, world, dist, args.mjpeg_frames)
-        assert ms["matches_single_process_totals"], ms
-        res["mjpeg_stream_1080p_422_q85"] = ms
-        mjpeg.release_stream_decoders()
-
     if rank == 0 and world == 1 and not args.no_workloads:
         # What a decode-only job gets that lays the metric's F frames out over three decoder objects with a stream
         # each (the narrow kernels of one part beside the wide ones of the others; a process has four hardware
-        # queues, so three such streams and no encoder beside them is as far as this goes).  Last of the GPU
-        # measurements: HIP maps streams to its hardware queues as they are first used, and the Motion JPEG
-        # pipeline above, measured after this, found its three streams serialised (46 k instead of 72 k frames/s).
+        # queues, so three such streams and no encoder beside them is as far as this goes).  Measured BEFORE the
+        # Motion JPEG pipelines on purpose: those must not depend on which streams the process used earlier (round 2:
+        # 46 k instead of 72 k frames/s in this order; their streams are now picked by measurement, binding.StreamSet).
         third = (F + 2) // 3
         parts = [jpgs[k:k + third] for k in range(0, F, third)]
         decs3, outs3 = [], []
@@ -522,6 +633,16 @@ def main():
         for dd in decs3:
             dd.close()
         del outs3
+
+    if not args.no_mjpeg:
+        ms = mjpeg_stream(torch, binding, synth, mjpeg, dev, rank, world, dist, args.mjpeg_frames)
+        assert ms["matches_single_process_totals"], ms
+        res["mjpeg_stream_1080p_422_q85"] = ms
+        mjpeg.release_stream_decoders()
+        es = mjpeg_encode_stream(torch, binding, synth, mjpeg, dev, rank, world, dist, args.mjpeg_frames)
+        res["mjpeg_stream_1080p_422_q85"].update({
+            "host_inclusive_encode_frames_per_s": es["host_inclusive_encode_frames_per_s"], "encode": es})
+        mjpeg.release_stream_decoders()
 
     if rank == 0 and world == 1 and not args.no_cpu:
         res["cpu_baseline"] = cpu_baseline(cpu_imgs, cpu_jpgs, cfg)

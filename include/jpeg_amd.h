@@ -173,6 +173,18 @@ void jpeg_hip_decoder_set_upload_stream(jpeg_hip_decoder *dec, void *stream, int
 /* compressed bytes actually consumed per frame (entropy-coded segment incl. RSTn), for roofline accounting */
 int  jpeg_hip_decoder_ecs_bytes(const jpeg_hip_decoder *dec, size_t *ecs_len);
 
+/* ---- streams for pipelines -----------------------------------------------------------------
+ * NO COUNTERPART IN THE REFERENCE (one thread, no device).  A process has four hardware queues, and HIP maps each
+ * stream to one of them in an order that depends on how many streams the process has made before; two streams of
+ * one queue do not overlap.  A pipeline that keeps several batches in flight (jpeg_amd/mjpeg.py: decode_stream,
+ * encode_stream) asks here for n <= 4 streams that were MEASURED to run side by side (two small kernels that note
+ * their start and end times), and -- use_avoid != 0 -- side by side with `avoid` too (the stream the caller's own
+ * work runs on; NULL = the null stream).  Returns how many of the n streams are proven to be on queues of their
+ * own (the rest, if the process has no free queue left, share), -1 on failure.  The streams are non-blocking
+ * hipStream_t; destroy them with jpeg_hip_streams_destroy(). */
+int  jpeg_hip_streams_create(int device, int n, void *avoid, int use_avoid, void **streams);
+void jpeg_hip_streams_destroy(int device, int n, void **streams);
+
 /* ---- Motion JPEG ---------------------------------------------------------------------------
  * "Supports Motion JPEG" in the reference means implicit Huffman tables (common.c:90-99); its
  * process_jpeg_stream() decodes ONE SOI..EOI codestream and reports what follows as garbage
@@ -218,6 +230,21 @@ int  jpeg_hip_encoder_info(const jpeg_hip_encoder *enc, jpeg_hip_frame_info *inf
 /* d_samples: nframes PPM/PGM bodies (u8, or big-endian u16 when P > 8), frame_stride bytes apart */
 int  jpeg_hip_encoder_run(jpeg_hip_encoder *enc, const void *d_samples, size_t frame_stride, void *stream);
 int  jpeg_hip_encoder_sync(jpeg_hip_encoder *enc, int *frame_status, size_t *jpg_len);
+/* Motion JPEG stream out (the encode direction).  The reference writes its one codestream
+ * to a FILE* as it goes (produce_codestream() encoder.c:589-645 through write_ecs_byte() io.c:277-290); a batch
+ * leaves the device as ONE run of bytes instead: run() as above, then the finished codestreams (SOI .. EOI) are
+ * packed back to back in frame order into out[0 .. cap) by kernels on the same stream -- a Motion JPEG stream as
+ * jpeg_hip_mjpeg_split() reads it.  `out` is device memory (the kernels pack straight into it) or page-locked host
+ * memory (jpeg_hip_host_alloc / hipHostMalloc: the kernels pack into a staging buffer of cap bytes in HBM, and
+ * sync_stream(), which knows the stream's length by then, brings exactly that many bytes over with one DMA on a
+ * copy stream of the encoder's own); anything else is refused with RET_FAILURE_LOGIC_ERROR.  run_stream() waits for
+ * nothing.  sync_stream() waits for that run (an event) and for its DMA, and returns the per-frame RET_* codes and
+ * frame_off[nframes + 1]: frame f occupies out[frame_off[f] .. frame_off[f + 1]), frame_off[nframes] is the
+ * stream's length.  A frame that failed takes no room.  A codestream that does not fit what is left of cap is
+ * dropped with RET_FAILURE_OVERFLOW_ERROR, and so is every frame behind it (the stream has no holes). */
+int  jpeg_hip_encoder_run_stream(jpeg_hip_encoder *enc, const void *d_samples, size_t frame_stride,
+                                 void *out, size_t cap, void *stream);
+int  jpeg_hip_encoder_sync_stream(jpeg_hip_encoder *enc, int *frame_status, size_t *frame_off);
 /* complete codestream (SOI .. EOI) of one frame copied to host memory */
 int  jpeg_hip_encoder_get_jpeg(jpeg_hip_encoder *enc, int frame, uint8_t *out, size_t cap, size_t *len);
 /* device-resident codestream of one frame (valid until the next run) */

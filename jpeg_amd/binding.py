@@ -34,6 +34,7 @@ EXPORTS = [
     "jpeg_hip_decoder_set_debug", "jpeg_hip_decoder_get_chain_steps", "jpeg_hip_decoder_set_tolerant", "jpeg_hip_decoder_set_upload_stream", "jpeg_hip_mjpeg_split",
     "jpeg_hip_encoder_create", "jpeg_hip_encoder_destroy", "jpeg_hip_encoder_configure",
     "jpeg_hip_encoder_info", "jpeg_hip_encoder_run", "jpeg_hip_encoder_sync",
+    "jpeg_hip_encoder_run_stream", "jpeg_hip_encoder_sync_stream",
     "jpeg_hip_encoder_get_jpeg", "jpeg_hip_encoder_device_jpeg", "jpeg_hip_encoder_get_coefficients",
     "jpeg_hip_encoder_set_timing", "jpeg_hip_encoder_get_timing",
     "jpeg_hip_process_jpeg_stream", "jpeg_hip_process_jpeg_file", "jpeg_hip_process_stream",
@@ -42,6 +43,7 @@ EXPORTS = [
     "jpeg_hip_encode_noalloc", "jpeg_hip_encode_noalloc_limit", "jpeg_hip_encode_noalloc_init",
     "jpeg_hip_selftest_divide",
     "jpeg_hip_selftest_ycc8",
+    "jpeg_hip_streams_create", "jpeg_hip_streams_destroy",
 ]
 
 
@@ -139,6 +141,8 @@ def lib():
         L.jpeg_hip_encoder_info.argtypes = [vp, C.POINTER(FrameInfo)]
         L.jpeg_hip_encoder_run.argtypes = [vp, vp, sz, vp]
         L.jpeg_hip_encoder_sync.argtypes = [vp, ip, C.POINTER(sz)]
+        L.jpeg_hip_encoder_run_stream.argtypes = [vp, vp, sz, vp, sz, vp]
+        L.jpeg_hip_encoder_sync_stream.argtypes = [vp, ip, C.POINTER(sz)]
         L.jpeg_hip_encoder_get_jpeg.argtypes = [vp, C.c_int, vp, sz, C.POINTER(sz)]
         L.jpeg_hip_encoder_device_jpeg.argtypes = [vp, C.c_int, C.POINTER(sz)]
         L.jpeg_hip_encoder_device_jpeg.restype = vp
@@ -157,6 +161,9 @@ def lib():
         L.jpeg_hip_encode_noalloc_limit.restype = sz
         L.jpeg_hip_selftest_divide.argtypes = [C.c_int, C.c_int, C.c_uint, C.POINTER(C.c_ulonglong)]
         L.jpeg_hip_selftest_ycc8.argtypes = [C.c_int, C.POINTER(C.c_ulonglong)]
+        L.jpeg_hip_streams_create.argtypes = [C.c_int, C.c_int, vp, C.c_int, C.POINTER(vp)]
+        L.jpeg_hip_streams_destroy.argtypes = [C.c_int, C.c_int, C.POINTER(vp)]
+        L.jpeg_hip_streams_destroy.restype = None
         L.jpeg_hip_set_qtable.argtypes = [vp, C.c_int, C.c_int]
         L.jpeg_hip_set_qtable.restype = None
         L.jpeg_hip_encoder_set_restart_interval.argtypes = [vp, C.c_int]
@@ -175,6 +182,26 @@ def _torch():
 def _stream_ptr(device):
     torch = _torch()
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+class StreamSet:
+    """n streams measured to run on hardware queues of their own, and beside the caller's current stream
+    (jpeg_hip_streams_create), as torch.cuda.ExternalStream objects.  `proven` = how many really are."""
+
+    def __init__(self, device, n, avoid_current=True):
+        torch = _torch()
+        self.L, self.device, self.n = lib(), device, n
+        self.raw = (C.c_void_p * n)()
+        avoid = _stream_ptr(device) if avoid_current else C.c_void_p()
+        self.proven = self.L.jpeg_hip_streams_create(device, n, avoid, int(avoid_current), self.raw)
+        if self.proven < 0:
+            raise JpegError(RET_FAILURE_LOGIC_ERROR, "jpeg_hip_streams_create")
+        self.streams = [torch.cuda.ExternalStream(int(self.raw[i]), device=device) for i in range(n)]
+
+    def close(self):
+        if self.raw is not None:
+            self.L.jpeg_hip_streams_destroy(self.device, self.n, self.raw)
+            self.raw, self.streams = None, []
 
 
 def _timing(fn, handle):
@@ -455,6 +482,28 @@ class Encoder:
         if err and not any(st):
             raise JpegError(err, "jpeg_hip_encoder_sync")  # failed before any frame status was written
         return list(st), list(ln)
+
+    def run_stream(self, samples, out, cap=None):
+        """run(), and the finished codestreams packed back to back into `out`: a PinnedBuffer (page-locked host
+        memory: the kernels store across the link) or a uint8 device tensor (jpeg_hip_encoder_run_stream)."""
+        if isinstance(out, PinnedBuffer):
+            addr, room = out.addr, out.nbytes
+        else:
+            addr, room = out.data_ptr(), out.numel()
+        cap = room if cap is None else min(cap, room)
+        err = self.L.jpeg_hip_encoder_run_stream(self.h, C.c_void_p(samples.data_ptr()), samples.stride(0),
+                                                 C.c_void_p(addr), cap, _stream_ptr(self.device))
+        if err:
+            raise JpegError(err, "jpeg_hip_encoder_run_stream")
+
+    def sync_stream(self):
+        """-> (per-frame status, frame_off[n + 1]): frame f is out[frame_off[f]:frame_off[f + 1]]."""
+        st = (C.c_int * self.n)()
+        off = (C.c_size_t * (self.n + 1))()
+        err = self.L.jpeg_hip_encoder_sync_stream(self.h, st, off)
+        if err and not any(st):
+            raise JpegError(err, "jpeg_hip_encoder_sync_stream")
+        return list(st), list(off)
 
     def jpeg(self, frame, length):
         buf = C.create_string_buffer(length)

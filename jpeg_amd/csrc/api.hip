@@ -992,6 +992,111 @@ extern "C" void jpeg_hip_host_free(void *p)
 	}
 }
 
+// ======================================================================================= streams on different hardware queues
+//
+// A process has four hardware queues (GPU_MAX_HW_QUEUES) and HIP maps every stream to one of them as streams come
+// into being: A B C D D C B A A B ... in order (measured, tools/queue_probe.hip).  Work on two streams of one queue
+// runs one piece after the other, so a pipeline that wants its batches side by side must not take "the next three
+// streams": which queues those land on depends on how many streams the process has made before (three in a row
+// from position 3 are D D C -- the Motion JPEG pipeline then ran at 46 k instead of 72 k frames/s).  This makes
+// candidates and MEASURES: two kernels that note the time when they start and end, one per stream; streams whose
+// kernels ran side by side are on different queues.
+__global__ void k_queue_probe(unsigned long long *stamp, long long ticks)
+{
+	const long long t0 = wall_clock64();
+	if (threadIdx.x == 0) {
+		stamp[0] = (unsigned long long)t0;
+	}
+	while (wall_clock64() - t0 < ticks) {
+	}
+	if (threadIdx.x == 0) {
+		stamp[1] = (unsigned long long)wall_clock64();
+	}
+}
+
+// did a kernel on b start before the kernel on a, launched first, ended?
+static bool streams_overlap(hipStream_t a, hipStream_t b, unsigned long long *h_stamp)
+{
+	const long long ticks = 20000;                         // wall_clock64() counts at 100 MHz: 200 us
+	memset(h_stamp, 0, 4 * sizeof *h_stamp);
+	hipLaunchKernelGGL(k_queue_probe, dim3(1), dim3(64), 0, a, h_stamp, ticks);
+	hipLaunchKernelGGL(k_queue_probe, dim3(1), dim3(64), 0, b, h_stamp + 2, ticks);
+	if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) {
+		return false;
+	}
+	return h_stamp[2] < h_stamp[1] && h_stamp[0] < h_stamp[3];
+}
+
+extern "C" int jpeg_hip_streams_create(int device, int n, void *avoid, int use_avoid, void **streams)
+{
+	int err = require_device(device);
+	if (err) {
+		return -1;
+	}
+	if (n < 1 || n > 4 || !streams) {
+		return -1;
+	}
+	const int ncand = 8;                                   // one period of the mapping: every queue is among them
+	hipStream_t cand[ncand];
+	int made = 0;
+	for (; made < ncand; ++made) {
+		if (hipStreamCreateWithFlags(&cand[made], hipStreamNonBlocking) != hipSuccess) {
+			break;
+		}
+	}
+	unsigned long long *h_stamp = nullptr;
+	if (made < n || hipHostMalloc((void **)&h_stamp, 4 * sizeof *h_stamp, hipHostMallocDefault) != hipSuccess) {
+		for (int i = 0; i < made; ++i) {
+			hipStreamDestroy(cand[i]);
+		}
+		(void)hipGetLastError();
+		return -1;
+	}
+	bool keep[ncand] = {false};
+	int kept[4], nkept = 0;
+	for (int c = 0; c < made && nkept < n; ++c) {
+		bool ok = !use_avoid || streams_overlap((hipStream_t)avoid, cand[c], h_stamp);
+		for (int k = 0; k < nkept && ok; ++k) {
+			ok = streams_overlap(cand[kept[k]], cand[c], h_stamp);
+		}
+		if (ok) {
+			kept[nkept++] = c;
+			keep[c] = true;
+		}
+	}
+	const int proven = nkept;
+	for (int c = 0; c < made && nkept < n; ++c) {          // fewer free queues than asked for: the rest share
+		if (!keep[c]) {
+			kept[nkept++] = c;
+			keep[c] = true;
+		}
+	}
+	for (int c = 0; c < made; ++c) {
+		if (!keep[c]) {
+			hipStreamDestroy(cand[c]);
+		}
+	}
+	hipHostFree(h_stamp);
+	for (int k = 0; k < n; ++k) {
+		streams[k] = (void *)cand[kept[k]];
+	}
+	return proven;
+}
+
+extern "C" void jpeg_hip_streams_destroy(int device, int n, void **streams)
+{
+	if (!streams || hipSetDevice(device) != hipSuccess) {
+		return;
+	}
+	for (int k = 0; k < n; ++k) {
+		if (streams[k]) {
+			hipStreamSynchronize((hipStream_t)streams[k]);
+			hipStreamDestroy((hipStream_t)streams[k]);
+			streams[k] = nullptr;
+		}
+	}
+}
+
 extern "C" int jpeg_hip_decoder_info(const jpeg_hip_decoder *dec, jpeg_hip_frame_info *info)
 {
 	if (!dec || dec->nframes == 0) {
@@ -1362,6 +1467,20 @@ struct jpeg_hip_encoder {
 	uint32_t *d_acdc = nullptr;
 	uint8_t *d_out = nullptr;
 	JhEncState *d_state = nullptr;
+	unsigned long long *d_soff = nullptr;   // stream out: where each frame went ([nframes + 1]) and how long it is
+	uint32_t *d_slen = nullptr;
+	// page-locked copies of what sync() reads: run() ends with asynchronous copies into them and an event
+	JhEncState *h_state = nullptr;
+	uint32_t *h_hdr_len = nullptr, *h_slen = nullptr;
+	unsigned long long *h_soff = nullptr;
+	hipEvent_t done = nullptr;
+	void *stream_dst = nullptr;       // run_stream(): where the kernels pack the codestreams (device memory), NULL after a plain run()
+	size_t stream_cap = 0;
+	void *host_dst = nullptr;         // run_stream() into page-locked host memory: sync_stream() sends the packed stream there
+	uint8_t *d_pack = nullptr;        // ... from this staging buffer, by DMA on copy_stream
+	size_t d_pack_cap = 0;
+	hipStream_t copy_stream = nullptr;
+	hipEvent_t copied = nullptr;
 	JhEncodeWork work;
 	hipStream_t last_stream = nullptr;
 	bool ran = false;
@@ -1375,6 +1494,13 @@ struct jpeg_hip_encoder {
 		hipFree(d_quant); hipFree(d_coefs); hipFree(d_codes); hipFree(d_hist); hipFree(d_wg_bits);
 		hipFree(d_us); hipFree(d_chunk_ff); hipFree(d_hdr_len); hipFree(d_bitlen); hipFree(d_nzmap); hipFree(d_acdc); hipFree(d_out); hipFree(d_state);
 		hipFree(d_ivl_raw); hipFree(d_ivl_padsum); hipFree(d_ivl_eb); hipFree(d_specs); hipFree(d_hdr_parts);
+		hipFree(d_soff); hipFree(d_slen); hipFree(d_pack);
+		d_pack = nullptr; d_pack_cap = 0;
+		if (h_state) { hipHostFree(h_state); }
+		if (h_hdr_len) { hipHostFree(h_hdr_len); }
+		if (h_slen) { hipHostFree(h_slen); }
+		if (h_soff) { hipHostFree(h_soff); }
+		d_soff = nullptr; d_slen = nullptr; h_state = nullptr; h_hdr_len = h_slen = nullptr; h_soff = nullptr;
 		d_specs = nullptr; d_hdr_parts = nullptr;
 		d_ivl_raw = d_ivl_padsum = d_ivl_eb = nullptr;
 		d_quant = nullptr; d_coefs = nullptr; d_codes = nullptr; d_hist = d_wg_bits = d_us = d_chunk_ff = d_hdr_len = nullptr;
@@ -1392,6 +1518,10 @@ extern "C" int jpeg_hip_encoder_create(jpeg_hip_encoder **enc, int device)
 	jpeg_hip_encoder *e = new jpeg_hip_encoder();
 	e->device = device;
 	memset(&e->g, 0, sizeof e->g);
+	if (hipSetDevice(device) != hipSuccess || hipEventCreateWithFlags(&e->done, hipEventDisableTiming) != hipSuccess) {
+		delete e;
+		return RET_FAILURE_LOGIC_ERROR;
+	}
 	*enc = e;
 	return RET_SUCCESS;
 }
@@ -1400,7 +1530,19 @@ extern "C" void jpeg_hip_encoder_destroy(jpeg_hip_encoder *enc)
 {
 	if (enc) {
 		hipSetDevice(enc->device);
+		if (enc->ran) {
+			hipEventSynchronize(enc->done);
+		}
 		enc->release();
+		if (enc->done) {
+			hipEventDestroy(enc->done);
+		}
+		if (enc->copied) {
+			hipEventDestroy(enc->copied);
+		}
+		if (enc->copy_stream) {
+			hipStreamDestroy(enc->copy_stream);
+		}
 		delete enc;
 	}
 }
@@ -1484,7 +1626,7 @@ static int encoder_configure(jpeg_hip_encoder *enc, int nframes, int X, int Y, i
 	}
 	HIPCHK(hipSetDevice(enc->device));
 	if (enc->ran) {
-		HIPCHK(hipStreamSynchronize(enc->last_stream));    // the buffers are about to be reused
+		HIPCHK(hipEventSynchronize(enc->done));            // the buffers are about to be reused
 	}
 	enc->ran = false;
 	enc->nframes = 0;                                      // not configured until everything below has succeeded
@@ -1557,8 +1699,14 @@ static int encoder_configure(jpeg_hip_encoder *enc, int nframes, int X, int Y, i
 	HIPCHK(hipMalloc((void **)&enc->d_bitlen, (size_t)nframes * g.nblk * sizeof(uint16_t)));
 	HIPCHK(hipMalloc((void **)&enc->d_nzmap, (size_t)nframes * g.nblk * sizeof(unsigned long long)));
 	HIPCHK(hipMalloc((void **)&enc->d_acdc, (size_t)nframes * g.nblk * sizeof(uint32_t)));
-	HIPCHK(hipMalloc((void **)&enc->d_out, (size_t)nframes * w.out_stride));
+	HIPCHK(hipMalloc((void **)&enc->d_out, (size_t)nframes * w.out_stride + 16));   // (+16: k_enc_stream_copy reads whole dwords)
 	HIPCHK(hipMalloc((void **)&enc->d_state, nframes * sizeof(JhEncState)));
+	HIPCHK(hipMalloc((void **)&enc->d_soff, ((size_t)nframes + 1) * sizeof(unsigned long long)));
+	HIPCHK(hipMalloc((void **)&enc->d_slen, (size_t)nframes * sizeof(uint32_t)));
+	HIPCHK(hipHostMalloc((void **)&enc->h_state, nframes * sizeof(JhEncState), hipHostMallocDefault));
+	HIPCHK(hipHostMalloc((void **)&enc->h_hdr_len, nframes * sizeof(uint32_t), hipHostMallocDefault));
+	HIPCHK(hipHostMalloc((void **)&enc->h_slen, nframes * sizeof(uint32_t), hipHostMallocDefault));
+	HIPCHK(hipHostMalloc((void **)&enc->h_soff, ((size_t)nframes + 1) * sizeof(unsigned long long), hipHostMallocDefault));
 	if (w.nivl > 0) {
 		HIPCHK(hipMalloc((void **)&enc->d_ivl_raw, (size_t)nframes * w.nivl * sizeof(uint32_t)));
 		HIPCHK(hipMalloc((void **)&enc->d_ivl_padsum, (size_t)nframes * (w.nivl + 1) * sizeof(uint32_t)));
@@ -1633,7 +1781,28 @@ extern "C" int jpeg_hip_encoder_info(const jpeg_hip_encoder *enc, jpeg_hip_frame
 	return RET_SUCCESS;
 }
 
-extern "C" int jpeg_hip_encoder_run(jpeg_hip_encoder *enc, const void *d_samples, size_t frame_stride, void *stream)
+// What sync() reads comes to page-locked memory behind the run, on its stream, and an event marks the end: sync()
+// waits for that event only (not for what the caller queued behind the run) and touches no stream.
+// stream_dst != NULL: the codestreams leave packed (k_enc_stream_*) in front of that.
+static int encoder_queue_results(jpeg_hip_encoder *enc, hipStream_t s, const JhTimerHook *th)
+{
+	const int n = enc->nframes;
+	if (enc->stream_dst) {
+		if (jh_launch_enc_stream(enc->work, enc->stream_dst, enc->stream_cap, enc->d_soff, enc->d_slen, s, th)) {
+			return RET_FAILURE_LOGIC_ERROR;
+		}
+		HIPCHK(hipMemcpyAsync(enc->h_soff, enc->d_soff, ((size_t)n + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+		HIPCHK(hipMemcpyAsync(enc->h_slen, enc->d_slen, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+	}
+	HIPCHK(hipMemcpyAsync(enc->h_state, enc->d_state, n * sizeof(JhEncState), hipMemcpyDeviceToHost, s));
+	if (enc->prm.optimize) {
+		HIPCHK(hipMemcpyAsync(enc->h_hdr_len, enc->d_hdr_len, n * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+	}
+	HIPCHK(hipEventRecord(enc->done, s));
+	return RET_SUCCESS;
+}
+
+static int encoder_run(jpeg_hip_encoder *enc, const void *d_samples, size_t frame_stride, void *stream, void *dst, size_t cap)
 {
 	if (!enc || enc->nframes == 0 || !d_samples) {
 		return RET_FAILURE_LOGIC_ERROR;
@@ -1644,7 +1813,13 @@ extern "C" int jpeg_hip_encoder_run(jpeg_hip_encoder *enc, const void *d_samples
 	}
 	HIPCHK(hipSetDevice(enc->device));
 	hipStream_t s = (hipStream_t)stream;
+	if (enc->ran) {
+		// the page-locked copies of the last run: read by sync() -- a caller that skipped it must not find them half overwritten
+		HIPCHK(hipEventSynchronize(enc->done));
+	}
 	enc->last_stream = s;
+	enc->stream_dst = dst;
+	enc->stream_cap = cap;
 	enc->timer.reset();
 	const JhEncodeWork &w = enc->work;
 	HIPCHK(hipMemsetAsync(enc->d_state, 0, enc->nframes * sizeof(JhEncState), s));
@@ -1668,8 +1843,68 @@ extern "C" int jpeg_hip_encoder_run(jpeg_hip_encoder *enc, const void *d_samples
 		return RET_FAILURE_LOGIC_ERROR;
 	}
 	enc->acbits_ready = acbits;
+	int err = encoder_queue_results(enc, s, &th);
+	if (err) {
+		return err;
+	}
 	enc->ran = true;
 	return RET_SUCCESS;
+}
+
+extern "C" int jpeg_hip_encoder_run(jpeg_hip_encoder *enc, const void *d_samples, size_t frame_stride, void *stream)
+{
+	if (enc) {
+		enc->host_dst = nullptr;
+	}
+	return encoder_run(enc, d_samples, frame_stride, stream, nullptr, 0);
+}
+
+// Motion JPEG stream out (the encode direction): see include/jpeg_amd.h
+extern "C" int jpeg_hip_encoder_run_stream(jpeg_hip_encoder *enc, const void *d_samples, size_t frame_stride,
+                                           void *out, size_t cap, void *stream)
+{
+	if (!enc || !out) {
+		return RET_FAILURE_LOGIC_ERROR;
+	}
+	HIPCHK(hipSetDevice(enc->device));
+	// the kernels store through `out`: it must be memory this device can write -- device memory, or page-locked host
+	// memory (a pointer into pageable memory would end in a memory access fault, not in an error code)
+	hipPointerAttribute_t at;
+	memset(&at, 0, sizeof at);
+	if (hipPointerGetAttributes(&at, out) != hipSuccess ||
+	    (at.type != hipMemoryTypeDevice && at.type != hipMemoryTypeHost && at.type != hipMemoryTypeManaged)) {
+		(void)hipGetLastError();
+		fprintf(stderr, "jpeg_amd: jpeg_hip_encoder_run_stream: `out` is neither device memory nor page-locked host memory "
+		                "(jpeg_hip_host_alloc)\n");
+		return RET_FAILURE_LOGIC_ERROR;
+	}
+	// Device memory: the kernels pack straight into it.  Host memory: they pack into a staging buffer in HBM, and
+	// sync_stream() -- which knows the stream's length by then -- sends exactly that many bytes over with ONE DMA.
+	// (Kernels that store across the link directly reach its rate too, 53 GB/s, but while they run the device runs
+	// nothing else: posted writes fill the fabric's queues and every other kernel's stores wait behind them --
+	// measured, three encoders on three queues took 3 x (2.9 + 2.3) ms per round.  The DMA engines do not.)
+	void *dev_view = out;
+	enc->host_dst = nullptr;
+	if (at.type == hipMemoryTypeHost) {
+		if (enc->ran) {
+			HIPCHK(hipEventSynchronize(enc->done));            // the staging buffer may be replaced
+		}
+		if (enc->d_pack_cap < cap) {
+			hipFree(enc->d_pack);
+			enc->d_pack = nullptr;
+			enc->d_pack_cap = 0;
+			HIPCHK(hipMalloc((void **)&enc->d_pack, cap ? cap : 1));
+			enc->d_pack_cap = cap;
+		}
+		if (!enc->copy_stream) {
+			HIPCHK(hipStreamCreateWithFlags(&enc->copy_stream, hipStreamNonBlocking));
+			HIPCHK(hipEventCreateWithFlags(&enc->copied, hipEventDisableTiming));
+		}
+		dev_view = enc->d_pack;
+	}
+	int err = encoder_run(enc, d_samples, frame_stride, stream, dev_view, cap);
+	enc->host_dst = !err && at.type == hipMemoryTypeHost ? out : nullptr;
+	return err;
 }
 
 // A frame's entropy-coded data did not fit the unstuffed stream or the output slot (noise at high quality: the
@@ -1702,7 +1937,7 @@ static int encoder_grow_streams(jpeg_hip_encoder *enc)
 	w.nchunk = (int)(us / 4096);
 	HIPCHK(hipMalloc((void **)&enc->d_us, (size_t)n * w.us_stride));
 	HIPCHK(hipMalloc((void **)&enc->d_chunk_ff, (size_t)n * w.nchunk * sizeof(uint32_t)));
-	HIPCHK(hipMalloc((void **)&enc->d_out, (size_t)n * w.out_stride));
+	HIPCHK(hipMalloc((void **)&enc->d_out, (size_t)n * w.out_stride + 16));
 	w.us = enc->d_us;
 	w.chunk_ff = enc->d_chunk_ff;
 	w.out = enc->d_out;
@@ -1731,10 +1966,27 @@ static int encoder_grow_streams(jpeg_hip_encoder *enc)
 	if (jh_launch_enc_entropy(w, g, s, nullptr, enc->acbits_ready)) {
 		return RET_FAILURE_LOGIC_ERROR;
 	}
-	return RET_SUCCESS;
+	return encoder_queue_results(enc, s, nullptr);
 }
 
+static int encoder_sync(jpeg_hip_encoder *enc, int *frame_status, size_t *jpg_len, size_t *frame_off);
+
 extern "C" int jpeg_hip_encoder_sync(jpeg_hip_encoder *enc, int *frame_status, size_t *jpg_len)
+{
+	return encoder_sync(enc, frame_status, jpg_len, nullptr);
+}
+
+extern "C" int jpeg_hip_encoder_sync_stream(jpeg_hip_encoder *enc, int *frame_status, size_t *frame_off)
+{
+	if (!enc || !enc->ran || !enc->stream_dst || !frame_off) {
+		return RET_FAILURE_LOGIC_ERROR;
+	}
+	return encoder_sync(enc, frame_status, nullptr, frame_off);
+}
+
+// frame_off != NULL: the run was a run_stream(); frame_off[nframes + 1] receives where each frame's codestream starts in
+// the packed stream (a failed frame takes no room: frame_off[f + 1] == frame_off[f])
+static int encoder_sync(jpeg_hip_encoder *enc, int *frame_status, size_t *jpg_len, size_t *frame_off)
 {
 	if (!enc || !enc->ran) {
 		return RET_FAILURE_LOGIC_ERROR;
@@ -1749,8 +2001,8 @@ extern "C" int jpeg_hip_encoder_sync(jpeg_hip_encoder *enc, int *frame_status, s
 	}
 	HIPCHK(hipSetDevice(enc->device));
 	for (int attempt = 0;; ++attempt) {
-		HIPCHK(hipStreamSynchronize(enc->last_stream));
-		HIPCHK(hipMemcpy(enc->state.data(), enc->d_state, enc->nframes * sizeof(JhEncState), hipMemcpyDeviceToHost));
+		HIPCHK(hipEventSynchronize(enc->done));            // this run, not what the caller queued behind it
+		memcpy(enc->state.data(), enc->h_state, enc->nframes * sizeof(JhEncState));   // run() brought them over
 		bool over = false;
 		for (int f = 0; f < enc->nframes; ++f) {
 			const JhEncState &st = enc->state[f];
@@ -1768,7 +2020,7 @@ extern "C" int jpeg_hip_encoder_sync(jpeg_hip_encoder *enc, int *frame_status, s
 		}
 	}
 	if (enc->prm.optimize) {
-		HIPCHK(hipMemcpy(enc->hdr_len.data(), enc->d_hdr_len, enc->nframes * sizeof(uint32_t), hipMemcpyDeviceToHost));
+		memcpy(enc->hdr_len.data(), enc->h_hdr_len, enc->nframes * sizeof(uint32_t));
 	}
 	int worst = RET_SUCCESS;
 	for (int f = 0; f < enc->nframes; ++f) {
@@ -1783,6 +2035,8 @@ extern "C" int jpeg_hip_encoder_sync(jpeg_hip_encoder *enc, int *frame_status, s
 			r = JPEG_HIP_ERR_NO_CODE;
 		} else if (st.status & JH_EST_OVERFLOW) {
 			r = RET_FAILURE_OVERFLOW_ERROR;
+		} else if (frame_off && enc->h_slen[f] == JH_STREAM_NOFIT) {
+			r = RET_FAILURE_OVERFLOW_ERROR;                    // a complete codestream, and no room left for it in `out`
 		}
 		if (frame_status) {
 			frame_status[f] = r;
@@ -1790,9 +2044,21 @@ extern "C" int jpeg_hip_encoder_sync(jpeg_hip_encoder *enc, int *frame_status, s
 		if (jpg_len) {
 			jpg_len[f] = r ? 0 : (size_t)enc->hdr_len[f] + st.ecs_bytes + 2;
 		}
+		if (frame_off) {
+			frame_off[f] = (size_t)enc->h_soff[f];
+			if (f == enc->nframes - 1) {
+				frame_off[f + 1] = (size_t)enc->h_soff[f + 1];
+			}
+		}
 		if (r && !worst) {
 			worst = r;
 		}
+	}
+	if (frame_off && enc->host_dst && enc->h_soff[enc->nframes] > 0) {
+		// the packed stream, exactly as long as it is, from the staging buffer to the caller's page-locked memory
+		HIPCHK(hipMemcpyAsync(enc->host_dst, enc->d_pack, (size_t)enc->h_soff[enc->nframes], hipMemcpyDeviceToHost, enc->copy_stream));
+		HIPCHK(hipEventRecord(enc->copied, enc->copy_stream));
+		HIPCHK(hipEventSynchronize(enc->copied));
 	}
 	return worst;
 }
@@ -2462,7 +2728,7 @@ extern "C" int jpeg_hip_encode_pixels(int device, const jpeg_hip_frame_desc *fra
 		} else if (st0.status & JH_EST_NO_CODE) {
 			err = RET_FAILURE_FILE_UNSUPPORTED;            // P > 12: a coefficient beyond 16 bits (see jpeg_amd.h)
 		}
-		enc->ran = !err;
+		enc->ran = !err && hipEventRecord(enc->done, nullptr) == hipSuccess;
 		for (int k = 0; k < g.ncomp && !err; ++k) {
 			if (coef[k]) {
 				err = jpeg_hip_encoder_get_coefficients(enc, 0, k, coef[k]);
@@ -2579,6 +2845,10 @@ extern "C" int jpeg_hip_write_scan(int device, const jpeg_hip_frame_desc *frame,
 	}
 	if (!err) {
 		enc->last_stream = nullptr;
+		enc->stream_dst = nullptr;
+		err = encoder_queue_results(enc, nullptr, nullptr);
+	}
+	if (!err) {
 		enc->ran = true;
 		int status = RET_SUCCESS;
 		size_t total = 0;

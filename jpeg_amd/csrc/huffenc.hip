@@ -31,6 +31,7 @@
 // kernels insert FF D0+(k mod 8) at the interval ends (markers are not stuffed).  Judge: the reference
 // decoder decodes these streams to the same samples (tests).
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include "common.hpp"
 #include "kernels.hpp"
 
@@ -1159,6 +1160,126 @@ int jh_launch_enc_entropy(const JhEncodeWork &w, const JhGeom &g, hipStream_t s,
 	JH_T_END(th, s);
 	JH_T_BEGIN(th, "k_enc_stuff", s);
 	hipLaunchKernelGGL(k_enc_stuff, dim3(ff_wgs, w.nframes), dim3(256), 0, s, a);
+	JH_T_END(th, s);
+	return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// ================================================================================== Motion JPEG stream out
+//
+// The reference writes its one codestream to a FILE* as it goes (produce_codestream, encoder.c:589-645, through
+// write_ecs_byte, io.c:277-290).  A batch of frames leaves the device as ONE run of bytes instead: the finished
+// codestreams (headers, entropy-coded data, EOI), back to back in frame order, with a table of offsets --
+// a Motion JPEG stream as jpeg_hip_mjpeg_split() reads it.  The destination is device memory; api.hip sends it on
+// to page-locked host memory by DMA when that is where the caller wants it.
+
+// One workgroup: the frames' lengths (0 for a frame that failed), their exclusive prefix, and which frames still
+// fit `cap`.  off[nframes] = the stream's length.  len[f] = JH_STREAM_NOFIT: codestream complete, no room.
+__global__ __launch_bounds__(256) void k_enc_stream_offsets(const JhEncodeWork w, unsigned long long cap,
+                                                            unsigned long long *off, uint32_t *len)
+{
+	__shared__ unsigned long long scratch[256];
+	__shared__ unsigned long long carry, endpos;
+	if (threadIdx.x == 0) {
+		carry = 0;
+		endpos = ~0ull;
+	}
+	__syncthreads();
+	for (int f0 = 0; f0 < w.nframes; f0 += 256) {
+		const int f = f0 + threadIdx.x;
+		unsigned long long n = 0;
+		if (f < w.nframes) {
+			const JhEncState st = w.state[f];
+			if (st.first_err == 0 && !(st.status & (JH_EST_DC_RANGE | JH_EST_NO_CODE | JH_EST_OVERFLOW))) {
+				n = (unsigned long long)w.hdr_len[f] + st.ecs_bytes + 2u;
+			}
+		}
+		// a frame that does not fit takes no room, and neither does any frame behind it (a stream with a hole
+		// would misplace what follows): inclusive scan of the lengths, cut where it passes cap
+		scratch[threadIdx.x] = n;
+		__syncthreads();
+		for (int d = 1; d < 256; d <<= 1) {
+			const unsigned long long v = threadIdx.x >= (unsigned)d ? scratch[threadIdx.x - d] : 0;
+			__syncthreads();
+			scratch[threadIdx.x] += v;
+			__syncthreads();
+		}
+		const unsigned long long incl = carry + scratch[threadIdx.x];
+		const unsigned long long total = carry + scratch[255];
+		__syncthreads();
+		if (f < w.nframes) {
+			const bool fits = incl <= cap;               // lengths are not negative: once false, false for every later frame
+			off[f] = fits ? incl - n : (cap < incl - n ? cap : incl - n);
+			len[f] = fits ? (uint32_t)n : (n ? JH_STREAM_NOFIT : 0u);
+			if (!fits && n) {
+				atomicMin(&endpos, incl - n);
+			}
+		}
+		if (threadIdx.x == 0) {
+			carry = total;
+		}
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) {
+		off[w.nframes] = endpos < carry ? endpos : carry;    // the stream's length: up to the first frame that did not fit
+	}
+}
+
+// Some workgroups (gridDim.x), each walking every frame and taking its share of the frame's 16-byte pieces: frame f's
+// bytes from its slot to dst + off[f].  The destination is written in aligned 16-byte pieces (one per thread, 4 KB
+// per workgroup step), the source read as aligned dwords and shifted into place; the up to 15 bytes in front of the
+// first and behind the last whole piece go byte by byte (the neighbouring frames write the rest of those pieces).
+__global__ __launch_bounds__(256) void k_enc_stream_copy(const JhEncodeWork w, uint8_t *dst, const unsigned long long *off,
+                                                         const uint32_t *len)
+{
+	for (int f = 0; f < w.nframes; ++f) {
+		const uint32_t n = len[f];
+		if (n == 0 || n == JH_STREAM_NOFIT) {
+			continue;
+		}
+		uint8_t *d = dst + off[f];
+		const uint8_t *src = w.out + (size_t)f * w.out_stride;         // 4096-aligned
+		const uint32_t head = min(n, (uint32_t)((16u - (uint32_t)(reinterpret_cast<uintptr_t>(d) & 15u)) & 15u));
+		const uint32_t npiece = (n - head) >> 4;
+		const uint32_t tail0 = head + (npiece << 4);
+		if ((unsigned)f % gridDim.x == blockIdx.x) {
+			if (threadIdx.x < head) {
+				d[threadIdx.x] = src[threadIdx.x];
+			}
+			if (threadIdx.x >= 32 && tail0 + (threadIdx.x - 32) < n) {
+				d[tail0 + (threadIdx.x - 32)] = src[tail0 + (threadIdx.x - 32)];
+			}
+		}
+		const uint32_t sh = head & 3u;                                 // the source's byte phase, the same for every piece
+		const uint32_t *sw = reinterpret_cast<const uint32_t *>(src + (head & ~3u));
+		uint4 *dw = reinterpret_cast<uint4 *>(d + head);
+		for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < npiece; i += gridDim.x * 256) {
+			const uint32_t *p = sw + 4 * (size_t)i;
+			uint4 v;
+			if (sh == 0) {
+				v = make_uint4(p[0], p[1], p[2], p[3]);
+			} else {
+				// bytes sh .. sh + 15 of five dwords; the fifth lies inside the allocation (16 spare bytes behind the
+				// last slot, api.hip)
+				const uint32_t a0 = p[0], a1 = p[1], a2 = p[2], a3 = p[3], a4 = p[4];
+				v = make_uint4(__builtin_amdgcn_alignbyte(a1, a0, sh), __builtin_amdgcn_alignbyte(a2, a1, sh),
+				               __builtin_amdgcn_alignbyte(a3, a2, sh), __builtin_amdgcn_alignbyte(a4, a3, sh));
+			}
+			dw[i] = v;
+		}
+	}
+}
+
+int jh_launch_enc_stream(const JhEncodeWork &w, void *dst, size_t cap, unsigned long long *off, uint32_t *len,
+                         hipStream_t s, const JhTimerHook *th)
+{
+	JH_T_BEGIN(th, "k_enc_stream", s);
+	hipLaunchKernelGGL(k_enc_stream_offsets, dim3(1), dim3(256), 0, s, w, (unsigned long long)cap, off, len);
+	static const int stream_wgs = [] {
+		const char *e = getenv("JPEG_AMD_STREAM_WGS");                  // experiments
+		const int v = e ? atoi(e) : 0;
+		return v > 0 && v <= 8192 ? v : 1024;
+	}();
+	hipLaunchKernelGGL(k_enc_stream_copy, dim3(stream_wgs), dim3(256), 0, s, w, (uint8_t *)dst, off, len);
 	JH_T_END(th, s);
 	return hipGetLastError() == hipSuccess ? 0 : -1;
 }

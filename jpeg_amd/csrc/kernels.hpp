@@ -185,3 +185,9 @@ int jh_launch_enc_headers(const JhEncodeWork &w, const JhGeom &g, hipStream_t s)
 // acbits_ready: the pixel kernel has filled w.nzmap / w.acdc with the codes in w.codes: the bit lengths then need
 // the DC symbols only (k_enc_dcbits); otherwise k_enc_bitlen walks the coefficients and fills both arrays
 int jh_launch_enc_entropy(const JhEncodeWork &w, const JhGeom &g, hipStream_t s, const JhTimerHook *th, bool acbits_ready);
+// Motion JPEG stream out: the finished codestreams of the batch back to back at dst (device memory, or page-locked
+// host memory the device can write), at most cap bytes; off[nframes + 1] / len[nframes] (device memory) receive
+// where each frame went and how long it is (0: the frame failed, JH_STREAM_NOFIT: no room left for it)
+#define JH_STREAM_NOFIT 0xffffffffu
+int jh_launch_enc_stream(const JhEncodeWork &w, void *dst, size_t cap, unsigned long long *off, uint32_t *len,
+                         hipStream_t s, const JhTimerHook *th);

@@ -76,8 +76,10 @@ def decode_stream(frames, batch=256, device=0):
     binding.PinnedFrames) while the kernels of this batch run on another stream; and the kernels of batch i+1 are
     queued BEFORE the caller waits for batch i, so the device does not idle while Python looks at statuses, and
     the narrow kernels at the end of one batch's synchronisation run beside the wide ones of the next.  No copy
-    streams: a process has four hardware queues.  Yields (tensor, status) in order; the tensor of a batch stays
-    valid until the batch after the next one has been yielded."""
+    streams: a process has four hardware queues.  Yields (tensor, status) in order.  sync() has waited for the batch,
+    so the consumer may use the tensor on its own (the current) stream at once; the tensor is the consumer's to keep or
+    drop -- its memory is handed back to the allocator only after the consumer's work queued so far has run
+    (record_stream)."""
     from concurrent.futures import ThreadPoolExecutor
     torch = binding._torch()
     decs, streams = _stream_decoders(device)
@@ -102,7 +104,12 @@ def decode_stream(frames, batch=256, device=0):
                 st = decs[i % n].sync()            # waits for batch i only (an event behind its last kernel)
                 if i + n < len(chunks):
                     futs[i + n] = pool.submit(decs[i % n].prepare, chunks[i + n])   # that decoder is free again
-                yield outs.pop(i), st
+                out = outs.pop(i)
+                # The tensor was allocated on the decoder's stream and is about to be used on the consumer's: tell the
+                # caching allocator, or the block goes back to that stream's pool the moment the consumer drops the
+                # tensor and the NEXT run() queued there may overwrite it under a consumer kernel still pending.
+                out.record_stream(torch.cuda.current_stream(device))
+                yield out, st
         finally:
             for fut in futs.values():
                 try:
@@ -111,12 +118,87 @@ def decode_stream(frames, batch=256, device=0):
                     pass
 
 
+def encode_stream(batches, X, Y, Nf, P=8, H=2, V=1, q=75, optimize=0, restart_interval=0, device=0, out_bytes=None):
+    """The encode direction of the stream layer (the reference writes its one codestream as
+    it goes, encoder.c:589-645): `batches` yields uint8 device tensors [n, frame_bytes] of PPM/PGM bodies (n may
+    vary up to the first batch's); every batch leaves the device as ONE run of bytes -- its codestreams back to
+    back in page-locked host memory, written by the encoder's last kernels across the link -- and is yielded as
+    (numpy uint8 view of that memory, frame_off[n + 1], per-frame status): frame f is view[off[f]:off[f + 1]], the
+    view is a Motion JPEG stream as split() reads it.  STREAM_DEPTH encoder objects take turns, a stream and a host
+    buffer each: batch i + 1 (and i + 2) is queued before batch i is waited for, so the stores of one batch cross
+    the link beside the kernels of the next.  The view of a batch stays valid until STREAM_DEPTH - 1 more batches
+    have been yielded.  out_bytes: room per batch in host memory (default: a quarter of the samples' bytes, at least
+    1 MB; a batch that needs more comes back with RET_FAILURE_OVERFLOW_ERROR for the frames that did not fit)."""
+    import numpy as np
+    torch = binding._torch()
+    encs, streams, bufs = _stream_encoders(device)
+    n = len(encs)
+    it = iter(batches)
+    pending = []                                   # (batch index, frames) queued and not yet yielded
+    cfg = {}
+
+    def queue(j, samples):
+        e = encs[j % n]
+        key = (int(samples.shape[0]), X, Y, Nf, P, H, V, q, optimize, restart_interval)
+        if cfg.get(j % n) != key:
+            e.configure(samples.shape[0], X, Y, Nf, P=P, H=H, V=V, q=q, optimize=optimize, restart_interval=restart_interval)
+            cfg[j % n] = key
+        want = out_bytes or max(1 << 20, samples.numel() // 4)
+        if bufs[j % n] is None or bufs[j % n].nbytes < want:
+            if bufs[j % n] is not None:
+                bufs[j % n].close()
+            bufs[j % n] = binding.PinnedBuffer(want)
+        st = streams[j % n]
+        st.wait_stream(torch.cuda.current_stream(device))     # the samples were made on the caller's stream
+        samples.record_stream(st)
+        with torch.cuda.stream(st):
+            e.run_stream(samples, bufs[j % n])
+        pending.append(j)
+
+    j = 0
+    for samples in it:
+        queue(j, samples)
+        j += 1
+        if len(pending) == n:                      # n - 1 batches stay in flight behind the one that is waited for
+            i = pending.pop(0)
+            st, off = encs[i % n].sync_stream()
+            yield np.frombuffer(bufs[i % n].view(), dtype=np.uint8)[:off[-1]], off, st
+    while pending:
+        i = pending.pop(0)
+        st, off = encs[i % n].sync_stream()
+        yield np.frombuffer(bufs[i % n].view(), dtype=np.uint8)[:off[-1]], off, st
+
+
+_enc_stream_state = {}
+
+
+def _stream_encoders(device):
+    """Encoder objects, streams and page-locked output buffers of encode_stream(), kept between calls."""
+    if device not in _enc_stream_state:
+        torch = binding._torch()
+        if not _stream_state and not _enc_stream_state:
+            import atexit
+            atexit.register(release_stream_decoders)
+        encs = [binding.Encoder(device) for _ in range(STREAM_DEPTH)]
+        _enc_stream_state[device] = (encs, _pipeline_streams(device), [None] * STREAM_DEPTH)
+    return _enc_stream_state[device]
+
+
 _stream_state = {}
-STREAM_DEPTH = int(__import__("os").environ.get("JPEG_AMD_STREAM_DEPTH", "3"))   # decoders (and streams) that take turns
-# 0 = normal.  A process that has had many streams busy before may find these three on ONE hardware queue (HIP maps
-# streams to its four queues as they are first used) and the pipeline serialised: 46 k instead of 72 k frames/s
-# measured; -1 (high priority: another set of queues) brought that case back to 67 - 73 k.  DESIGN.md section 5.
-STREAM_PRIORITY = int(__import__("os").environ.get("JPEG_AMD_STREAM_PRIORITY", "0"))
+_stream_sets = {}
+STREAM_DEPTH = int(__import__("os").environ.get("JPEG_AMD_STREAM_DEPTH", "3"))   # decoders / encoders (and streams) that take turns
+
+
+def _pipeline_streams(device):
+    """STREAM_DEPTH streams that were MEASURED to run side by side and beside the caller's stream
+    (jpeg_hip_streams_create): HIP maps streams to its four hardware queues in an order that depends on how many the
+    process made before, and three streams taken in a row can land two on one queue -- the pipeline then ran at 46 k
+    instead of 72 k frames/s in a process that had used other streams first.  One set per
+    device, shared by the decode and the encode pipeline."""
+    if device not in _stream_sets:
+        _stream_sets[device] = binding.StreamSet(device, min(4, STREAM_DEPTH))
+    s = _stream_sets[device].streams
+    return [s[i % len(s)] for i in range(STREAM_DEPTH)]
 
 
 def _stream_decoders(device):
@@ -125,11 +207,11 @@ def _stream_decoders(device):
     frames (hipHostMalloc of 150 MB pins every page).  release_stream_decoders() frees them."""
     if device not in _stream_state:
         torch = binding._torch()
-        if not _stream_state:
+        if not _stream_state and not _enc_stream_state:
             import atexit
             atexit.register(release_stream_decoders)   # while the HIP runtime is still there
         decs = [binding.Decoder(device) for _ in range(STREAM_DEPTH)]
-        streams = [torch.cuda.Stream(device=device, priority=STREAM_PRIORITY) for _ in range(STREAM_DEPTH)]
+        streams = _pipeline_streams(device)
         for d, st in zip(decs, streams):
             d.set_upload_stream(st)
         _stream_state[device] = (decs, streams)
@@ -141,6 +223,16 @@ def release_stream_decoders():
         for d in decs:
             d.close()
     _stream_state.clear()
+    for encs, _, bufs in _enc_stream_state.values():
+        for e in encs:
+            e.close()
+        for b in bufs:
+            if b is not None:
+                b.close()
+    _enc_stream_state.clear()
+    for ss in _stream_sets.values():
+        ss.close()
+    _stream_sets.clear()
 
 
 def gather_stats(local, dist=None):

@@ -28,6 +28,21 @@ def load(dirname):
     return {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in acc.items()}
 
 
+def tree_tag():
+    """what the summary is tagged with: git HEAD and a hash of the kernel sources (bench.py compares the latter with
+    the tree it runs on and says so loudly when a kernel has changed since the counters were collected)"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    try:
+        head = subprocess.check_output(["git", "-C", root, "rev-parse", "--short=12", "HEAD"], text=True).strip()
+        dirty = bool(subprocess.check_output(["git", "-C", root, "status", "--porcelain", "jpeg_amd/csrc"], text=True).strip())
+    except Exception:
+        head, dirty = None, None
+    return {"head": head, "csrc_dirty": dirty, "csrc_sha16": bench.csrc_sha16()}
+
+
 def main():
     root, frames, out = sys.argv[1], int(sys.argv[2]), sys.argv[3]
     merged = defaultdict(dict)
@@ -56,7 +71,7 @@ def main():
             d["lds_bank_conflict_share"] = round(c.get("SQ_LDS_BANK_CONFLICT", 0.0) / c["SQ_LDS_IDX_ACTIVE"], 4)
         res[k] = {"counters": r, "derived": d}
     json.dump({"command": "rocprofv3 --pmc <SQ counters, three passes: tools/profile.sh> -- python3 bench.py --steps 1 --warmup 0 "
-                          "--no-cpu --no-mjpeg --no-workloads --one-stream", "frames_per_launch": frames, "kernels": res},
+                          "--no-cpu --no-mjpeg --no-workloads --one-stream", "frames_per_launch": frames, "kernels": res, **tree_tag()},
               open(out, "w"), indent=1, sort_keys=True)
     for k, v in res.items():
         print("%-20s %s" % (k, json.dumps(v["derived"])))
