@@ -268,13 +268,13 @@ def mjpeg_stream(torch, binding, synth, mjpeg, dev, rank, world, dist, batch, di
 
     # (a) the rank's part of the file in ONE page-locked buffer (what an I/O layer that owns its buffers delivers:
     # every byte is read from DRAM by the DMA engine, no staging copy); (b) frames as pageable Python bytes objects
-    # (the library copies them into its pinned staging buffer with a few threads, then DMA).  Three passes each:
-    # the first creates workspaces, the others show the run-to-run spread.
+    # (the library copies them into its pinned staging buffer with a few threads, then DMA).  Three passes each,
+    # taking turns: the first of each kind creates workspaces, the others show the run-to-run spread.
     pinned = binding.PinnedFrames.from_frames(mine)
     mine = [bytes(bytearray(j)) for j in mine]             # every frame its own pageable memory (not 32 cache-warm objects)
     runs = {"pinned": [], "pageable": []}
-    for kind, src in (("pinned", pinned), ("pageable", mine)):
-        for attempt in range(3):
+    for attempt in range(3):                               # interleaved: neither kind gets the warmer device
+        for kind, src in (("pinned", pinned), ("pageable", mine)):
             n, tot, t_rank, t_all = timed_pass(src)
             runs[kind].append((t_rank, t_all))
     pinned.buf.close()

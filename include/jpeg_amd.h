@@ -250,6 +250,15 @@ int  jpeg_hip_encoder_get_jpeg(jpeg_hip_encoder *enc, int frame, uint8_t *out, s
 /* device-resident codestream of one frame (valid until the next run) */
 const void *jpeg_hip_encoder_device_jpeg(jpeg_hip_encoder *enc, int frame, size_t *len);
 int  jpeg_hip_encoder_get_coefficients(jpeg_hip_encoder *enc, int frame, int k, int32_t *out);
+/* Stage taps at the reference's FLOAT stage boundaries, for parity tests (the fused kernels never store them
+ * otherwise).  d_floats = device memory the next run() also fills, NULL = off (default):
+ *   decoder: frame->data behind frame_to_rgb() (frame.c:188-244), before roundf() / clamp (frame.c:375-380): per frame
+ *            Y rows of X pixels of 1 (PGM) or 3 (PPM) floats -- the visible part of the reference's padded frame;
+ *   encoder: component[].frame_buffer behind transform_frame_to_components() (frame.c:84-132), before the level shift of
+ *            forward_dct() (imgproc.c:220-222): per frame the component planes one after the other, by*8 rows of bx*8
+ *            floats each (jpeg_hip_encoder_info). */
+void jpeg_hip_decoder_set_float_tap(jpeg_hip_decoder *dec, void *d_floats);
+void jpeg_hip_encoder_set_float_tap(jpeg_hip_encoder *enc, void *d_floats);
 void jpeg_hip_encoder_set_timing(jpeg_hip_encoder *enc, int on);
 int  jpeg_hip_encoder_get_timing(jpeg_hip_encoder *enc, const char **names, float *ms, int cap);
 

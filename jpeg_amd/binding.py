@@ -44,6 +44,7 @@ EXPORTS = [
     "jpeg_hip_selftest_divide",
     "jpeg_hip_selftest_ycc8",
     "jpeg_hip_streams_create", "jpeg_hip_streams_destroy",
+    "jpeg_hip_decoder_set_float_tap", "jpeg_hip_encoder_set_float_tap",
 ]
 
 
@@ -164,6 +165,9 @@ def lib():
         L.jpeg_hip_streams_create.argtypes = [C.c_int, C.c_int, vp, C.c_int, C.POINTER(vp)]
         L.jpeg_hip_streams_destroy.argtypes = [C.c_int, C.c_int, C.POINTER(vp)]
         L.jpeg_hip_streams_destroy.restype = None
+        for fn in (L.jpeg_hip_decoder_set_float_tap, L.jpeg_hip_encoder_set_float_tap):
+            fn.argtypes = [vp, vp]
+            fn.restype = None
         L.jpeg_hip_set_qtable.argtypes = [vp, C.c_int, C.c_int]
         L.jpeg_hip_set_qtable.restype = None
         L.jpeg_hip_encoder_set_restart_interval.argtypes = [vp, C.c_int]
@@ -348,6 +352,17 @@ class Decoder:
             raise JpegError(err, "jpeg_hip_decoder_run")
         return out
 
+    def set_float_tap(self, on=True):
+        """Stage tap: the next run() also stores the samples as floats before rounding (frame->data behind
+        frame_to_rgb, frame.c:188-244) -> float32 tensor [n, Y, X, 1 or 3] (returned), None = off."""
+        torch = _torch()
+        self.tap = None
+        if on:
+            i = self.info
+            self.tap = torch.zeros((self.n, i.Y, i.X, i.out_components), dtype=torch.float32, device="cuda:%d" % self.device)
+        self.L.jpeg_hip_decoder_set_float_tap(self.h, C.c_void_p(self.tap.data_ptr() if on else None))
+        return self.tap
+
     def sync(self):
         st = (C.c_int * self.n)()
         err = self.L.jpeg_hip_decoder_sync(self.h, st)
@@ -482,6 +497,24 @@ class Encoder:
         if err and not any(st):
             raise JpegError(err, "jpeg_hip_encoder_sync")  # failed before any frame status was written
         return list(st), list(ln)
+
+    def set_float_tap(self, on=True):
+        """Stage tap: the next run() also stores the component planes behind the down-sampling, before the level
+        shift (component[].frame_buffer, frame.c:84-132) -> list of float32 views [n, by*8, bx*8] per component."""
+        torch = _torch()
+        self.tap = None
+        if not on:
+            self.L.jpeg_hip_encoder_set_float_tap(self.h, None)
+            return None
+        i = self.info
+        sizes = [i.by[k] * 8 * i.bx[k] * 8 for k in range(i.Nf)]
+        self.tap = torch.zeros((self.n, sum(sizes)), dtype=torch.float32, device="cuda:%d" % self.device)
+        self.L.jpeg_hip_encoder_set_float_tap(self.h, C.c_void_p(self.tap.data_ptr()))
+        views, at = [], 0
+        for k in range(i.Nf):
+            views.append(self.tap[:, at:at + sizes[k]].reshape(self.n, i.by[k] * 8, i.bx[k] * 8))
+            at += sizes[k]
+        return views
 
     def run_stream(self, samples, out, cap=None):
         """run(), and the finished codestreams packed back to back into `out`: a PinnedBuffer (page-locked host

@@ -225,6 +225,7 @@ struct DecPass {
 struct jpeg_hip_decoder {
 	int device = 0;
 	int nframes = 0;
+	float *float_tap = nullptr;               // stage tests: see jpeg_hip_decoder_set_float_tap()
 	JhGeom g;
 	std::vector<DecPass> pass;
 	std::vector<int> parse_err;
@@ -1143,7 +1144,7 @@ static int decoder_launch(jpeg_hip_decoder *dec, hipStream_t s)
 	}
 	if (!dec->coefs_only) {                                // jpeg_hip_read_scan: the coefficients are the result
 		dec->timer.begin("k_decode_pixels", s);
-		if (jh_launch_decode_pixels(dec->g, dec->nframes, dec->d_coefs, dec->d_quant, dec->last_out, dec->last_stride, s)) {
+		if (jh_launch_decode_pixels(dec->g, dec->nframes, dec->d_coefs, dec->d_quant, dec->last_out, dec->last_stride, s, dec->float_tap)) {
 			return RET_FAILURE_LOGIC_ERROR;
 		}
 		dec->timer.end(s);
@@ -1414,6 +1415,13 @@ extern "C" int jpeg_hip_decoder_get_chain_steps(jpeg_hip_decoder *dec, int frame
 	return RET_SUCCESS;
 }
 
+extern "C" void jpeg_hip_decoder_set_float_tap(jpeg_hip_decoder *dec, void *d_floats)
+{
+	if (dec) {
+		dec->float_tap = (float *)d_floats;
+	}
+}
+
 extern "C" void jpeg_hip_decoder_set_debug(jpeg_hip_decoder *dec, int flags)
 {
 	dec->debug = flags;
@@ -1476,6 +1484,7 @@ struct jpeg_hip_encoder {
 	hipEvent_t done = nullptr;
 	void *stream_dst = nullptr;       // run_stream(): where the kernels pack the codestreams (device memory), NULL after a plain run()
 	size_t stream_cap = 0;
+	float *float_tap = nullptr;       // stage tests: see jpeg_hip_encoder_set_float_tap()
 	void *host_dst = nullptr;         // run_stream() into page-locked host memory: sync_stream() sends the packed stream there
 	uint8_t *d_pack = nullptr;        // ... from this staging buffer, by DMA on copy_stream
 	size_t d_pack_cap = 0;
@@ -1828,7 +1837,7 @@ static int encoder_run(jpeg_hip_encoder *enc, const void *d_samples, size_t fram
 	// default tables: the codes are known, and the pixel kernel counts every block's AC bits while it holds the block
 	const bool acbits = !enc->prm.optimize;
 	if (jh_launch_encode_pixels(g, enc->nframes, d_samples, frame_stride, enc->d_quant, enc->d_coefs, enc->d_nzmap, enc->d_acdc,
-	                            acbits ? enc->d_codes : nullptr, enc->d_state, s)) {
+	                            acbits ? enc->d_codes : nullptr, enc->d_state, s, enc->float_tap)) {
 		return RET_FAILURE_LOGIC_ERROR;
 	}
 	enc->timer.end(s);
@@ -2098,6 +2107,13 @@ extern "C" int jpeg_hip_encoder_get_coefficients(jpeg_hip_encoder *enc, int fram
 	HIPCHK(hipMemcpy(fc.data(), enc->d_coefs + (size_t)frame * n, n * sizeof(int16_t), hipMemcpyDeviceToHost));
 	coefs_to_reference_layout(enc->g, fc.data(), k, out);
 	return RET_SUCCESS;
+}
+
+extern "C" void jpeg_hip_encoder_set_float_tap(jpeg_hip_encoder *enc, void *d_floats)
+{
+	if (enc) {
+		enc->float_tap = (float *)d_floats;
+	}
 }
 
 extern "C" void jpeg_hip_encoder_set_timing(jpeg_hip_encoder *enc, int on) { enc->timer.on = on != 0; }

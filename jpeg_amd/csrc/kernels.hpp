@@ -106,7 +106,7 @@ int jh_launch_huff_sync(const JhDecodeWork &w, const JhGeom &g, hipStream_t s, c
 int jh_launch_huff_decode(const JhDecodeWork &w, const JhGeom &g, hipStream_t s, const JhTimerHook *th);
 
 int jh_launch_decode_pixels(const JhGeom &g, int nframes, const int16_t *coefs, const JhQuant *quant,
-                            void *out, size_t frame_stride, hipStream_t stream);
+                            void *out, size_t frame_stride, hipStream_t stream, float *tap = nullptr);
 // What the entropy encoder wants to know about a block besides its coefficients: the map of its nonzero
 // coefficients (bit k: coefficient k in zig-zag order) and one word (`acdc`) with the bits its AC symbols will
 // take in the low half (write_ac, coeffs.c:164-194, EOB / ZRL included; JH_ACBITS_NOCODE: a symbol has no code,
@@ -121,7 +121,10 @@ int jh_launch_decode_pixels(const JhGeom &g, int nframes, const int16_t *coefs, 
 // the AC code sizes of codes[frame * 4 + 2 + Ta]
 int jh_launch_encode_pixels(const JhGeom &g, int nframes, const void *in, size_t frame_stride,
                             const JhQuant *quant_raster, int16_t *coefs, unsigned long long *nzmap, uint32_t *acdc,
-                            const JhHuffEnc *codes, struct JhEncState *state, hipStream_t stream);
+                            const JhHuffEnc *codes, struct JhEncState *state, hipStream_t stream, float *tap = nullptr);
+// tap (both launchers): NULL, or device memory that receives the float stage boundary of the reference the kernel
+// crosses -- decode: frame->data behind frame_to_rgb (frame.c:188-244), [frame][Y][X][1 or 3]; encode: the component
+// planes behind transform_frame_to_components (frame.c:84-132), [frame][planes of by*8 x bx*8] -- for the stage tests
 
 int jh_launch_selftest_divide(unsigned long long *d_out, int per, unsigned seed, hipStream_t stream);
 int jh_launch_selftest_ycc8(unsigned long long *d_out, hipStream_t stream);

@@ -253,6 +253,7 @@ struct DecPixArgs {
 	const JhQuant *quant;      // [frame], zig-zag order
 	uint8_t *out;              // PPM/PGM bodies
 	size_t frame_stride;
+	float *tap;                // NULL, or [frame][Y][X][1 or 3]: the samples as floats before rounding (stage tests)
 	TileLayout L;
 	JhGeom g;
 };
@@ -458,6 +459,16 @@ __global__ __launch_bounds__(256) void k_decode_pixels(const DecPixArgs a)
 			}
 		}
 		const int npx = min(4, X - gx0);
+		if (a.tap) {
+			// stage tap (tests only): frame->data behind frame_to_rgb (frame.c:188-244), the visible part, 1 or 3 channels
+			float *tp = a.tap + (((size_t)f * Y + gy) * X + gx0) * oc;
+#pragma unroll
+			for (int i = 0; i < 4 * oc; ++i) {
+				if (i < npx * oc) {
+					tp[i] = ov[i];
+				}
+			}
+		}
 		uint8_t *p = org + (__umul24((unsigned)row, rowbytes) + __umul24((unsigned)px0, pxbytes));
 		const bool whole = npx == 4 && ((reinterpret_cast<uintptr_t>(p) & 3) == 0);
 		if (g.P == 8 && whole) {
@@ -528,13 +539,14 @@ __global__ __launch_bounds__(256) void k_decode_pixels(const DecPixArgs a)
 }
 
 int jh_launch_decode_pixels(const JhGeom &g, int nframes, const int16_t *coefs, const JhQuant *quant,
-                            void *out, size_t frame_stride, hipStream_t stream)
+                            void *out, size_t frame_stride, hipStream_t stream, float *tap)
 {
 	DecPixArgs a;
 	a.coefs = coefs;
 	a.quant = quant;
 	a.out = (uint8_t *)out;
 	a.frame_stride = frame_stride;
+	a.tap = tap;
 	make_layout(g, &a.L);
 	a.g = g;
 	dim3 grid((g.m_x + a.L.G - 1) / a.L.G, g.m_y, nframes);
@@ -577,6 +589,8 @@ struct EncPixArgs {
 	uint32_t *acdc;            // [frame][nblk] (with codes)
 	JhEncState *state;         // [frame], or NULL: a coefficient that does not fit 16 bits is reported there
 	const JhHuffEnc *codes;    // [frame][4] the codes in force for the frame, or NULL
+	float *tap;                // NULL, or [frame][component planes, by*8 rows of bx*8]: the planes behind the down-sampling,
+	                           // before the level shift (stage tests)
 	TileLayout L;
 	JhGeom g;
 };
@@ -643,7 +657,8 @@ __device__ __forceinline__ void load4(const uint8_t *org, unsigned rowbytes, int
 // start on dword boundaries (every group of an aligned frame): dword loads, no padding rule, no per-pixel tests.
 template <int NF, int SX, int SY, int SB, bool Y8, bool WHOLE>
 __device__ __forceinline__ void encode_group(float *tile, const TileLayout &L, const uint8_t *org, unsigned rowbytes,
-                                             int rg, int px0, int gx0, int my, int X, int Y, int shift, float shiftf)
+                                             int rg, int px0, int gx0, int my, int X, int Y, int shift, float shiftf,
+                                             float *tapf, const JhGeom &g)
 {
 	float ch[2][SY][4];
 #pragma unroll
@@ -705,6 +720,14 @@ __device__ __forceinline__ void encode_group(float *tile, const TileLayout &L, c
 		}
 		*reinterpret_cast<float4 *>(tile + L.base[0] + (int)__umul24((unsigned)row, (unsigned)L.pitch[0]) + px0) =
 			make_float4(y4[0], y4[1], y4[2], y4[3]);
+		if (tapf) {
+			// stage tap (tests only): component[0].frame_buffer behind transform_frame_to_components (frame.c:84-132)
+			float *tp = tapf + (size_t)gy * (g.bx[0] * 8) + gx0;
+#pragma unroll
+			for (int i = 0; i < 4; ++i) {
+				tp[i] = s[i][0];
+			}
+		}
 	}
 	if constexpr (NF == 3) {
 #pragma unroll
@@ -726,6 +749,13 @@ __device__ __forceinline__ void encode_group(float *tile, const TileLayout &L, c
 				}
 				px /= (float)(SY * SX);
 				o[ox] = px - shiftf;
+				if (tapf) {
+					size_t base = (size_t)g.by[0] * 8 * g.bx[0] * 8;
+					if (c == 1) {
+						base += (size_t)g.by[1] * 8 * g.bx[1] * 8;
+					}
+					tapf[base + (size_t)(my * (L.TH / SY) + rg) * (g.bx[c + 1] * 8) + gx0 / SX + ox] = px;
+				}
 			}
 			float *dst = tile + L.base[c + 1] + (int)__umul24((unsigned)rg, (unsigned)L.pitch[c + 1]) + px0 / SX;
 			if constexpr (SX == 1) {
@@ -812,6 +842,11 @@ __global__ __launch_bounds__(256) void k_encode_pixels(const EncPixArgs a)
 
 	// ---- 1: (row group, 4 pixels): samples -> float, RGB -> YCbCr, box mean, level shift --------
 	{
+		size_t plane_floats = 0;
+		for (int c = 0; c < NF; ++c) {
+			plane_floats += (size_t)g.by[c] * 8 * g.bx[c] * 8;
+		}
+		float *tapf = a.tap ? a.tap + (size_t)f * plane_floats : nullptr;
 		const int qpr = L.TW >> 2;
 		const int wpx = nmcu_here * 8 * g.max_H;
 		const int ngroups = (L.TH / SY) * qpr;
@@ -831,9 +866,9 @@ __global__ __launch_bounds__(256) void k_encode_pixels(const EncPixArgs a)
 				whole = whole && load4_whole<NF>(org, rowbytes, px0, rg * SY + sy, X, Y, SB, gx0, my * L.TH + rg * SY + sy);
 			}
 			if (whole) {
-				encode_group<NF, SX, SY, SB, Y8, true>(tile, L, org, rowbytes, rg, px0, gx0, my, X, Y, shift, shiftf);
+				encode_group<NF, SX, SY, SB, Y8, true>(tile, L, org, rowbytes, rg, px0, gx0, my, X, Y, shift, shiftf, tapf, g);
 			} else {
-				encode_group<NF, SX, SY, SB, Y8, false>(tile, L, org, rowbytes, rg, px0, gx0, my, X, Y, shift, shiftf);
+				encode_group<NF, SX, SY, SB, Y8, false>(tile, L, org, rowbytes, rg, px0, gx0, my, X, Y, shift, shiftf, tapf, g);
 			}
 		}
 	}
@@ -1033,9 +1068,10 @@ __global__ __launch_bounds__(256) void k_encode_pixels(const EncPixArgs a)
 
 int jh_launch_encode_pixels(const JhGeom &g, int nframes, const void *in, size_t frame_stride,
                             const JhQuant *quant_raster, int16_t *coefs, unsigned long long *nzmap, uint32_t *acdc,
-                            const JhHuffEnc *codes, JhEncState *state, hipStream_t stream)
+                            const JhHuffEnc *codes, JhEncState *state, hipStream_t stream, float *tap)
 {
 	EncPixArgs a;
+	a.tap = tap;
 	a.in = (const uint8_t *)in;
 	a.frame_stride = frame_stride;
 	a.quant = quant_raster;

@@ -130,6 +130,7 @@ void orc_image_free(orc_image *img)
 	}
 	for (int k = 0; k < ORC_MAXC; ++k) {
 		free(img->comp[k].coef);
+		free(img->plane[k]);
 	}
 	free(img->frame);
 	free(img);
@@ -1439,7 +1440,7 @@ int orc_encode(const uint8_t *body, int X, int Y, int Nf, int P, int H, int V, i
 				orc_quantize_block(&c->coef[(by * c->bx + bx) * 64], f, img->Q[c->Tq]);
 			}
 		}
-		free(plane);
+		img->plane[k] = plane;      /* kept for the stage tests (tests/: float stage boundaries) */
 		plane = NULL;
 	}
 
@@ -1776,6 +1777,7 @@ void orc_img_comp(const orc_image *img, int k, int *id, int *H, int *V, int *Tq,
 const int32_t *orc_img_coef(const orc_image *img, int k) { return img->comp[k].coef; }
 const uint16_t *orc_img_qtable(const orc_image *img, int t) { return img->Q[t & 3]; }
 const float *orc_img_frame(const orc_image *img) { return img->frame; }
+const float *orc_img_plane(const orc_image *img, int k) { return k >= 0 && k < ORC_MAXC ? img->plane[k] : NULL; }
 
 void orc_img_htable(const orc_image *img, int Tc, int Th, uint8_t L[16], uint8_t V[256])
 {

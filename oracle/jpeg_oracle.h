@@ -48,6 +48,8 @@ typedef struct {
 	size_t mblocks;            /* MCUs processed in the last scan */
 	int Ri;
 	float *frame;              /* interleaved float samples before roundf/clamp (size_y*size_x*Nf) */
+	float *plane[ORC_MAXC];    /* encode: component planes behind transform_frame_to_components (frame.c:84-132),
+	                              by*8 rows of bx*8 floats, before the level shift */
 } orc_image;
 
 /* ---- whole-codec entry points ------------------------------------------------ */
@@ -83,6 +85,7 @@ void orc_img_comp(const orc_image *img, int k, int *id, int *H, int *V, int *Tq,
 const int32_t *orc_img_coef(const orc_image *img, int k);
 const uint16_t *orc_img_qtable(const orc_image *img, int t);
 const float *orc_img_frame(const orc_image *img);
+const float *orc_img_plane(const orc_image *img, int k);
 void orc_img_htable(const orc_image *img, int Tc, int Th, uint8_t L[16], uint8_t V[256]);
 
 /* ---- block / table primitives (KATs) ----------------------------------------- */

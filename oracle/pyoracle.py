@@ -69,6 +69,7 @@ class _Image:
         self.comps = []      # dicts: id,H,V,Tq,bx,by,coef (int32 [by*bx,64] raster order)
         self.qtables = None  # uint16 [4,64] raster order
         self.frame = None    # float32 [size_y,size_x,Nf] before rounding (decode only)
+        self.planes = None   # encode only: float32 [by*8, bx*8] per component behind the down-sampling, before the level shift
         self.htables = None
         self.mblocks = 0
 
@@ -91,6 +92,8 @@ class Oracle:
         L.orc_img_qtable.restype = C.POINTER(C.c_uint16)
         L.orc_img_frame.argtypes = [C.c_void_p]
         L.orc_img_frame.restype = C.POINTER(C.c_float)
+        L.orc_img_plane.argtypes = [C.c_void_p, C.c_int]
+        L.orc_img_plane.restype = C.POINTER(C.c_float)
         L.orc_img_htable.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_char_p]
         L.orc_decode_coeff.restype = C.c_int32
         L.orc_decode_coeff.argtypes = [C.c_int, C.c_int]
@@ -118,6 +121,10 @@ class Oracle:
         fp = L.orc_img_frame(h)
         if fp:
             img.frame = np.ctypeslib.as_array(fp, shape=(img.size_y, img.size_x, img.Nf)).copy()
+        pl = [L.orc_img_plane(h, k) for k in range(ncomp)]
+        if all(pl):
+            img.planes = [np.ctypeslib.as_array(pl[k], shape=(img.comps[k]["by"] * 8, img.comps[k]["bx"] * 8)).copy()
+                          for k in range(ncomp)]
         img.htables = {}
         for tc in range(2):
             for th in range(4):
@@ -274,6 +281,11 @@ class Reference:
             img.comps.append(dict(id=ci[0].value, H=ci[1].value, V=ci[2].value, Tq=ci[3].value,
                                   bx=bx, by=by, coef=coef))
         img.qtables = np.stack([np.ctypeslib.as_array(lib.ref_tap_qtable(t), shape=(64,)).copy() for t in range(4)])
+        if lib is self.E and hasattr(lib, "ref_tap_plane"):
+            lib.ref_tap_plane.argtypes = [C.c_int]
+            lib.ref_tap_plane.restype = C.POINTER(C.c_float)
+            img.planes = [np.ctypeslib.as_array(lib.ref_tap_plane(k), shape=(c["by"] * 8, c["bx"] * 8)).copy()
+                          for k, c in enumerate(img.comps)]
 
     def decode(self, jpg):
         """-> (err, samples array or None, image info).  Runs decoder.c:661 process_jpeg_stream."""

@@ -34,6 +34,7 @@ static struct {
 	int id[TAP_MAXC], H[TAP_MAXC], V[TAP_MAXC], Tq[TAP_MAXC];
 	size_t bx[TAP_MAXC], by[TAP_MAXC];
 	int32_t *coef[TAP_MAXC];
+	float *plane[TAP_MAXC];       /* component[].frame_buffer: the planes behind transform_frame_to_components (frame.c:84-132) */
 	uint16_t Q[4][64];
 } tap;
 
@@ -41,6 +42,7 @@ static void tap_reset(void)
 {
 	for (int k = 0; k < TAP_MAXC; ++k) {
 		free(tap.coef[k]);
+		free(tap.plane[k]);
 	}
 	memset(&tap, 0, sizeof tap);
 }
@@ -61,6 +63,9 @@ int __wrap_quantize(struct context *context)
 			tap.bx[k] = c->b_x; tap.by[k] = c->b_y;
 			tap.coef[k] = malloc(blocks * 64 * sizeof(int32_t));
 			memcpy(tap.coef[k], c->int_buffer, blocks * 64 * sizeof(int32_t));
+			/* conv_frame_to_blocks() (imgproc.c:264-293) only read it: still what the down-sampling left */
+			tap.plane[k] = malloc(blocks * 64 * sizeof(float));
+			memcpy(tap.plane[k], c->frame_buffer, blocks * 64 * sizeof(float));
 		}
 	}
 	return err;
@@ -125,6 +130,8 @@ void ref_tap_comp_info(int k, int *id, int *H, int *V, int *Tq, size_t *bx, size
 }
 
 const int32_t *ref_tap_coef(int k) { return tap.coef[k]; }
+
+const float *ref_tap_plane(int k) { return tap.plane[k]; }
 
 const uint16_t *ref_tap_qtable(int t) { return tap.Q[t]; }
 

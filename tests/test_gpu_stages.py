@@ -219,3 +219,59 @@ def test_colour_conversion_without_binary64_on_all_rgb_triples(hip):
     out = (C.c_ulonglong * 3)()
     assert hip.lib().jpeg_hip_selftest_ycc8(0, out) == 0
     assert [int(v) for v in out] == [1 << 24, 0, 0], [int(v) for v in out]
+
+
+@pytest.mark.parametrize("X,Y,nc,P,H,V,q", [(83, 61, 3, 8, 2, 2, 75), (64, 48, 3, 8, 2, 1, 90), (40, 40, 3, 8, 1, 1, 50),
+                                            (50, 37, 3, 8, 1, 2, 85), (72, 40, 1, 8, 1, 1, 80), (48, 32, 3, 12, 2, 2, 90),
+                                            (33, 17, 1, 12, 1, 1, 90)])
+def test_float_stage_boundaries_bit_for_bit(hip, oracle, X, Y, nc, P, H, V, q):
+    """The two FLOAT stage boundaries of the reference that the fused kernels cross, tapped on the device and compared
+    bit for bit with the oracle (which tests/test_oracle_vs_ref.py pins to the compiled reference at the same places):
+    encode -- component[].frame_buffer behind frame_to_ycc + transform_frame_to_components (frame.c:84-186), padding
+    included (quirk Q7); decode -- frame->data behind frame_to_rgb (frame.c:188-244), before roundf / clamp."""
+    img = synth_image(X, Y, nc, P, seed=X + Y, range_safe=P > 8)
+    err, jpg, oinfo = oracle.encode(img, P=P, H=H, V=V, q=q, optimize=1)
+    assert err == 0
+    e = hip.Encoder()
+    e.configure(2, X, Y, nc, P, H, V, q, 1)
+    planes = e.set_float_tap(True)
+    e.run(e.upload([img, img]))
+    assert e.sync()[0] == [0, 0]
+    assert len(planes) == len(oinfo.planes)
+    for k, want in enumerate(oinfo.planes):
+        for f in range(2):
+            got = planes[k][f].cpu().numpy()
+            assert got.shape == want.shape
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), "plane %d of frame %d" % (k, f)
+    e.set_float_tap(False)
+    e.close()
+    err, opx, dinfo = oracle.decode(jpg)
+    assert err == 0
+    d = hip.Decoder()
+    d.prepare([jpg, jpg])
+    tap = d.set_float_tap(True)
+    out = d.run()
+    assert d.sync() == [0, 0]
+    oc = 1 if nc == 1 else 3
+    want = dinfo.frame[:Y, :X, :oc]
+    for f in range(2):
+        got = tap[f].cpu().numpy()
+        assert np.array_equal(got.view(np.uint32), np.ascontiguousarray(want).view(np.uint32)), "frame %d" % f
+    d.set_float_tap(False)
+    d.close()
+
+
+def test_float_frame_of_a_four_component_file(hip, oracle):
+    """YCCK (frame.c:196-217): the first three channels of frame->data behind frame_to_rgb, Pillow-written CMYK golden."""
+    from tests.conftest import golden_path
+    jpg = open(golden_path("d_pil_cmyk.jpg"), "rb").read()
+    err, opx, dinfo = oracle.decode(jpg)
+    assert err == 0 and dinfo.Nf == 4
+    d = hip.Decoder()
+    d.prepare([jpg])
+    tap = d.set_float_tap(True)
+    d.run()
+    assert d.sync() == [0]
+    want = np.ascontiguousarray(dinfo.frame[:dinfo.Y, :dinfo.X, :3])
+    assert np.array_equal(tap[0].cpu().numpy().view(np.uint32), want.view(np.uint32))
+    d.close()

@@ -60,6 +60,10 @@ def test_encode_decode_bit_exact(oracle, reference, case):
     assert _same_coefs(i1, i2)                       # quantised coefficients
     assert np.array_equal(i1.qtables[:2], i2.qtables[:2])
     assert j1 == j2                                  # whole codestream incl. DHT of the K.2 optimiser
+    # float planes behind transform_frame_to_components (component[].frame_buffer, frame.c:84-132), padding included
+    assert i2.planes is not None and len(i1.planes) == len(i2.planes)
+    for a, b in zip(i1.planes, i2.planes):
+        assert a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32))
     e1, s1, d1 = oracle.decode(j2)
     e2, s2, d2 = reference.decode(j2)
     assert e1 == 0 and e2 == 0
