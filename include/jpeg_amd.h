@@ -79,6 +79,11 @@ typedef struct jpeg_hip_frame_info {
 /* Number of usable HIP devices (0 = none: every entry point below then fails loudly). */
 int jpeg_hip_device_count(void);
 const char *jpeg_hip_version(void);
+/* Bumped whenever a structure or a signature of this header changes incompatibly (2: jpeg_hip_params lost
+ * restart_interval; 3: additions only).  A binding compares jpeg_hip_abi_version() with the JPEG_HIP_ABI_VERSION it
+ * was built against and refuses to go on when the library is older or has another layout of jpeg_hip_params. */
+#define JPEG_HIP_ABI_VERSION 3
+int jpeg_hip_abi_version(void);
 
 /* Host only, no GPU needed: the headers of one codestream up to its first SOS, as parse_format() reads them
  * (decoder.c:472-601: SOI, APPn, DQT, SOF0/SOF1, DHT, DRI, SOS), and the geometry that follows from them
@@ -279,9 +284,10 @@ int  jpeg_hip_encoder_get_timing(jpeg_hip_encoder *enc, const char **names, floa
  * All calls on one GPU share that GPU's array: calls that overlap in time on one GPU (two streams, two
  * threads) race -- serialise them. */
 size_t jpeg_hip_encode_noalloc_limit(void);
-/* optional set-up, once per device, OUTSIDE the caller's no-allocation region: the runtime loads the library's
- * code object on the device here and the fixed array comes into being with it (otherwise that happens inside
- * the first jpeg_hip_encode_noalloc() call on the device) */
+/* Set-up, once per device, OUTSIDE the caller's no-allocation region: the runtime loads the library's code object on
+ * the device here and the fixed array comes into being with it, and its address is looked up.  MANDATORY before a
+ * call under HIP graph capture (that look-up is not a capturable operation; tests/test_zz_no_alloc.py captures and
+ * replays the call); otherwise optional -- the first jpeg_hip_encode_noalloc() on a device does it itself. */
 int jpeg_hip_encode_noalloc_init(int device);
 int jpeg_hip_encode_noalloc(int device, const jpeg_hip_params *params, int X, int Y, int Nf, int P,
                             const void *d_samples, void *d_jpeg, size_t cap, uint32_t *d_result, void *stream);

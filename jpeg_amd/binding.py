@@ -23,9 +23,10 @@ JPEG_HIP_ERR_DC_RANGE = 0x5001
 JPEG_HIP_ERR_NO_CODE = -1
 
 MAX_COMP = 4
+ABI_VERSION = 3          # JPEG_HIP_ABI_VERSION of include/jpeg_amd.h this file mirrors
 
 EXPORTS = [
-    "jpeg_hip_device_count", "jpeg_hip_version", "jpeg_hip_parse_info",
+    "jpeg_hip_device_count", "jpeg_hip_version", "jpeg_hip_abi_version", "jpeg_hip_parse_info",
     "jpeg_hip_decoder_create", "jpeg_hip_decoder_destroy", "jpeg_hip_decoder_prepare",
     "jpeg_hip_decoder_prepare_pinned", "jpeg_hip_host_alloc", "jpeg_hip_host_free",
     "jpeg_hip_decoder_info", "jpeg_hip_decoder_frame_bytes", "jpeg_hip_decoder_run",
@@ -107,6 +108,9 @@ def lib():
         L = C.CDLL(LIB_PATH)
         vp, sz, ip = C.c_void_p, C.c_size_t, C.POINTER(C.c_int)
         L.jpeg_hip_version.restype = C.c_char_p
+        if L.jpeg_hip_abi_version() != ABI_VERSION:
+            raise RuntimeError("%s has ABI %d, this binding was written for %d (include/jpeg_amd.h: JPEG_HIP_ABI_VERSION)"
+                               % (LIB_PATH, L.jpeg_hip_abi_version(), ABI_VERSION))
         L.jpeg_hip_parse_info.argtypes = [C.c_char_p, sz, C.c_int, C.POINTER(FrameInfo)]
         L.jpeg_hip_decoder_create.argtypes = [C.POINTER(vp), C.c_int]
         L.jpeg_hip_decoder_destroy.argtypes = [vp]

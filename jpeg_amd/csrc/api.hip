@@ -4,6 +4,8 @@
 // kernel launches.  Everything pixel- or coefficient-sized stays resident in HBM between stages.
 // There is no CPU fallback: without a usable HIP device every entry point fails loudly.
 #include <hip/hip_runtime.h>
+#include <sched.h>
+#include <system_error>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -45,7 +47,11 @@ extern "C" int jpeg_hip_device_count(void)
 	return n;
 }
 
-extern "C" const char *jpeg_hip_version(void) { return "jpeg_amd 0.1 (gfx950)"; }
+// ABI 3 (round 3): jpeg_hip_encoder_run_stream / sync_stream, jpeg_hip_streams_create / destroy, the float taps,
+// jpeg_hip_selftest_ycc8 added; nothing removed.  ABI 2 (round 2): jpeg_hip_params lost its restart_interval member
+// (now jpeg_hip_encoder_set_restart_interval) -- a caller built against the older header must be rebuilt.
+extern "C" const char *jpeg_hip_version(void) { return "jpeg_amd 0.3 (gfx950, ABI 3)"; }
+extern "C" int jpeg_hip_abi_version(void) { return JPEG_HIP_ABI_VERSION; }
 
 // host only (no device needed): frames of a Motion JPEG stream
 extern "C" int jpeg_hip_mjpeg_split(const uint8_t *stream, size_t len, size_t *frame_off, size_t *frame_len, int cap)
@@ -219,6 +225,38 @@ struct DecPass {
 		d_rec = d_prec = nullptr; d_meta = nullptr; d_surv = nullptr; d_key01 = nullptr; d_wg_agg = d_wg_base = nullptr; d_wg_key = nullptr;
 	}
 };
+
+// Threads that fill the staging buffer of a prepare() from pageable memory (this one included): at most 6, and no more
+// than this process's share of the host -- the CPUs it may run on (sched_getaffinity) divided by the ranks that
+// share the node (LOCAL_WORLD_SIZE / WORLD_SIZE of torch.distributed.run; one process per GPU), less one for the
+// caller's own thread.  8 ranks on a 16-core share: 1 thread each beside Python's, instead of 8 x 6 = 48.
+// JPEG_AMD_FILL_THREADS overrides.
+static int fill_threads()
+{
+	static const int n = [] {
+		if (const char *e = getenv("JPEG_AMD_FILL_THREADS")) {
+			const int v = atoi(e);
+			if (v >= 1 && v <= 64) {
+				return v;
+			}
+		}
+		int cpus = (int)std::thread::hardware_concurrency();
+		cpu_set_t set;
+		if (sched_getaffinity(0, sizeof set, &set) == 0) {
+			cpus = CPU_COUNT(&set);
+		}
+		int ranks = 1;
+		for (const char *name : {"LOCAL_WORLD_SIZE", "WORLD_SIZE"}) {
+			if (const char *e = getenv(name)) {
+				ranks = atoi(e) > 0 ? atoi(e) : 1;
+				break;
+			}
+		}
+		const int share = cpus / ranks - 1;
+		return share < 1 ? 1 : (share > 6 ? 6 : share);
+	}();
+	return n;
+}
 
 #define JH_UPLOAD_PIECE (8u << 20)     // bytes per DMA of a batch that is uploaded from caller-pinned memory
 
@@ -833,7 +871,7 @@ static int decoder_prepare(jpeg_hip_decoder *dec, int nframes, const uint8_t *co
 		}
 		uint8_t *stage = dec->h_stage;
 		const size_t total = dec->raw_bytes;
-		const int nthr = total > (8u << 20) && nframes >= 16 ? 6 : 1;
+		const int nthr = total > (8u << 20) && nframes >= 16 ? fill_threads() : 1;
 		const int npiece = nthr == 1 ? 1 : (nframes < 4 * nthr ? nthr : 4 * nthr);
 		auto piece_first = [&](int pc) { return (int)((long long)nframes * pc / npiece); };
 		std::vector<std::atomic<int>> filled(npiece);
@@ -861,11 +899,16 @@ static int decoder_prepare(jpeg_hip_decoder *dec, int nframes, const uint8_t *co
 			}
 		};
 		std::vector<std::thread> pool;
-		for (int t = 1; t < nthr; ++t) {
-			pool.emplace_back(fill);
+		try {
+			for (int t = 1; t < nthr; ++t) {
+				pool.emplace_back(fill);
+			}
+		} catch (const std::system_error &) {
+			// no more threads to be had: the ones that exist and this one fill every piece (nothing may be thrown
+			// through the C boundary)
 		}
 		hipError_t up = hipSuccess;
-		if (nthr == 1) {
+		if (pool.empty()) {
 			fill();
 		}
 		for (int pc = 0; pc < npiece; ++pc) {

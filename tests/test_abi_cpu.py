@@ -112,3 +112,16 @@ def test_header_is_plain_c99_and_links(built_lib, tmp_path):
     r = subprocess.run([exe, os.path.join(ROOT, "tests", "golden", "d_pil_progressive.jpg")], capture_output=True,
                        text=True, timeout=60)
     assert r.returncode == 1 and "RET 0x1001" in r.stdout
+
+
+def test_abi_version_matches_header_and_binding(built_lib):
+    """jpeg_hip_params changed layout without a version bump.  The header, the library and the Python
+    binding carry one ABI number; binding.lib() refuses a library with another."""
+    hdr = open(os.path.join(ROOT, "include", "jpeg_amd.h")).read()
+    want = int(re.search(r"#define JPEG_HIP_ABI_VERSION (\d+)", hdr).group(1))
+    L = C.CDLL(built_lib.LIB_PATH)
+    assert L.jpeg_hip_abi_version() == want == built_lib.ABI_VERSION
+    L.jpeg_hip_version.restype = C.c_char_p
+    assert ("ABI %d" % want).encode() in L.jpeg_hip_version()
+    # struct params of the reference (encoder.c:68-76): H, V, q, optimize and nothing else
+    assert C.sizeof(built_lib.Params) == 12

@@ -87,3 +87,39 @@ def test_noalloc_limits_and_errors(hip):
     # and the array still serves the next call
     want, _ = hip.encode([img], P=8, H=2, V=2, q=75, optimize=1)
     assert noalloc(hip, torch, img, 8, 2, 2, 75, 1)[2] == want[0]
+
+
+def test_noalloc_captured_into_a_graph_and_replayed(hip):
+    """The use the header names first: the call captured into a HIP graph (no allocation, no copy, no host wait inside)
+    and replayed, also on new samples in the same buffer.  jpeg_hip_encode_noalloc_init() must have run before the
+    capture starts (the fixture does): the fixed array's address is looked up there."""
+    import torch
+    L = hip.lib()
+    # mandatory for this use: the fixed array's address is looked up here, outside the capture
+    assert L.jpeg_hip_encode_noalloc_init(0) == 0
+    X, Y, Nf, P, H, V, q, opt = 320, 200, 3, 8, 2, 2, 85, 0
+    imgs = [synth_image(X, Y, Nf, P, seed=s) for s in (5, 6)]
+    want, st = hip.encode(imgs, P=P, H=H, V=V, q=q, optimize=opt)
+    assert st == [0, 0]
+    body = torch.frombuffer(bytearray(pnm_body(imgs[0], P)), dtype=torch.uint8).cuda()
+    other = torch.frombuffer(bytearray(pnm_body(imgs[1], P)), dtype=torch.uint8).cuda()
+    cap = X * Y * Nf * 2 + 65536
+    out = torch.zeros(cap, dtype=torch.uint8, device="cuda")
+    res = torch.full((2,), 0x7fffffff, dtype=torch.int32, device="cuda")
+    prm = hip.Params(H, V, q, opt)
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    with torch.cuda.graph(g, stream=side):
+        err = L.jpeg_hip_encode_noalloc(0, C.byref(prm), X, Y, Nf, P, C.c_void_p(body.data_ptr()),
+                                        C.c_void_p(out.data_ptr()), cap, C.c_void_p(res.data_ptr()),
+                                        C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert err == 0
+    for k in range(2):
+        out.zero_()
+        res.fill_(0x7fffffff)
+        g.replay()
+        torch.cuda.synchronize()
+        status, length = (int(v) for v in res.cpu().tolist())
+        assert status == 0 and bytes(out[:length].cpu().numpy().tobytes()) == want[k]
+        body.copy_(other)                                # the graph reads the same buffer: new samples, same launch
