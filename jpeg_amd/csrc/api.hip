@@ -204,7 +204,7 @@ struct DecPass {
 	JhHuffLut *d_luts = nullptr;
 	std::vector<JhHuffLut> luts;
 	size_t cs_off = 0, seg_off = 0, chunk_off = 0, sub_off = 0, wg_off = 0;
-	uint32_t max_chunks = 1, max_subs = 1, max_luts = 1;
+	uint32_t max_chunks = 1, max_subs = 1, max_luts = 1, lut_bytes = sizeof(JhHuffLut);
 	int segmented = 0;                // a frame's scan came with a restart interval (DRI)
 	uint32_t sub_shift = JH_SUBSEQ_SHIFT; // log2 of the bits per sub-sequence of this pass
 	JhDecodeWork work{};
@@ -629,6 +629,7 @@ static int decoder_prepare(jpeg_hip_decoder *dec, int nframes, const uint8_t *co
 		ps.cs_off = ps.seg_off = ps.chunk_off = ps.sub_off = ps.wg_off = 0;
 		ps.segmented = 0;
 		ps.max_chunks = ps.max_subs = ps.max_luts = 1;
+		ps.lut_bytes = sizeof(JhHuffLut);
 		JhRemap rm;
 		memset(&rm, 0, sizeof rm);
 		rm.nblk_full = G.nblk;
@@ -777,6 +778,18 @@ static int decoder_prepare(jpeg_hip_decoder *dec, int nframes, const uint8_t *co
 			ps.max_chunks = fr.nchunk > ps.max_chunks ? fr.nchunk : ps.max_chunks;
 			ps.max_subs = fr.sub_cap > ps.max_subs ? fr.sub_cap : ps.max_subs;
 			ps.max_luts = fr.n_lut > ps.max_luts ? fr.n_lut : ps.max_luts;
+			{
+				// what load_tables() (huffcore.hpp) lays out in LDS: a slot that some block uses as its DC table is short
+				uint32_t bytes = 0;
+				for (uint32_t sl = 0; sl < fr.n_lut; ++sl) {
+					bool isdc = false;
+					for (int b = 0; b < ps.g.B; ++b) {
+						isdc = isdc || fr.blk_dc[b] == sl;
+					}
+					bytes += isdc ? JH_LUT_DC_BYTES : (uint32_t)sizeof(JhHuffLut);
+				}
+				ps.lut_bytes = bytes > ps.lut_bytes ? bytes : ps.lut_bytes;
+			}
 			ps.cs_off += cs_cap;
 			ps.sub_off += fr.sub_cap;
 			ps.seg_off += fr.seg_cap;
@@ -956,6 +969,7 @@ static int decoder_prepare(jpeg_hip_decoder *dec, int nframes, const uint8_t *co
 		w.max_chunks = ps.max_chunks;
 		w.max_subs = ps.max_subs;
 		w.max_luts = ps.max_luts;
+		w.lut_bytes = ps.lut_bytes;
 		w.debug = dec->debug;
 		w.segmented = ps.segmented;
 		w.sub_shift = ps.sub_shift;

@@ -4,6 +4,7 @@
 // parsing (decoder.c:20-259, 472-659; io.c:186-220), Annex C table generation (huffman.c:45-178),
 // the Annex K.2 optimiser (huffman.c:330-537), quality scaling (encoder.c:38-65) and header
 // production (encoder.c:195-400).  None of this is worth a kernel (<= a few KB per frame).
+#include <stddef.h>
 #include <string.h>
 #include "../../include/jpeg_amd.h"
 #include "codestream.hpp"
@@ -123,6 +124,8 @@ int jh_build_declut(const JhHuffSpec *s, int tc, JhHuffLut *lut)
 		return err;
 	}
 	static_assert(sizeof(JhHuffLut) % 16 == 0, "table offsets are kept in units of 16 bytes");
+	static_assert(offsetof(JhHuffLut, sub) == JH_LUT_DC_BYTES && JH_LUT_DC_BYTES % 16 == 0, "short form of a DC table");
+	static_assert(offsetof(JhHuffLut, pair) == JH_LUT_PAIR_OFF, "pair[] is read at a fixed distance from fast[]");
 	memset(lut, 0, sizeof *lut);
 	memcpy(lut->huffval, s->V, 256);
 	// query_code() (huffman.c:193-225) returns the FIRST table entry that matches; canonical
@@ -150,7 +153,8 @@ int jh_build_declut(const JhHuffSpec *s, int tc, JhHuffLut *lut)
 		const unsigned prefix = ((unsigned)c.code[p] >> (len - JH_LUT_BITS)) & ((1u << JH_LUT_BITS) - 1u);
 		uint16_t &f = lut->fast[prefix];
 		if (f == 0) {
-			f = nsub < JH_SUB_TABLES ? (uint16_t)(0x8000u | (unsigned)nsub++) : (uint16_t)JH_LUT_SEARCH;
+			// (DC tables: no second-level tables -- the kernels' copy of a DC table ends in front of them)
+			f = tc == 1 && nsub < JH_SUB_TABLES ? (uint16_t)(0x8000u | (unsigned)nsub++) : (uint16_t)JH_LUT_SEARCH;
 		}
 		if (!(f & 0x8000u)) {
 			continue;                                          // prefix taken by a shorter code (malformed table)
@@ -170,6 +174,29 @@ int jh_build_declut(const JhHuffSpec *s, int tc, JhHuffLut *lut)
 	for (unsigned i = 0; i < (1u << JH_LUT_BITS); ++i) {
 		if (lut->fast[i] == 0) {
 			lut->fast[i] = (uint16_t)JH_LUT_INVALID;           // no code starts with these bits
+		}
+	}
+	// AC tables: the symbol BEHIND the window's first one, where its code lies inside the window too (common.hpp).
+	// The bits of the window behind the first symbol (its magnitude bits included) index the table once more, the
+	// unknown bits behind the window as zeros: the entry found there is the second symbol iff its code is no longer
+	// than the bits that are known.
+	if (tc == 1) {
+		for (unsigned i = 0; i < (1u << JH_LUT_BITS); ++i) {
+			const uint32_t e1 = lut->fast[i];
+			const unsigned total1 = e1 >> 10, run1 = (e1 >> 4) & 63u;
+			if ((e1 & 0x8000u) || run1 == 63u || total1 >= JH_LUT_BITS) {
+				continue;                                      // long code / none, EOB, or nothing of the window left
+			}
+			const unsigned known = JH_LUT_BITS - total1;
+			const uint32_t e2 = lut->fast[(i << total1) & ((1u << JH_LUT_BITS) - 1u)];
+			if (e2 & 0x8000u) {
+				continue;
+			}
+			const unsigned total2 = e2 >> 10, run2 = (e2 >> 4) & 63u, cat2 = e2 & 15u;
+			if (total2 - cat2 > known || total1 + total2 > 31u) {
+				continue;                                      // the code reaches past the window
+			}
+			lut->pair[i] = (uint16_t)(((total1 + total2) << 11) | ((run1 + 1u + run2) << 4) | cat2);
 		}
 	}
 	// slow path: left-aligned upper limits per length (canonical MAXCODE of F.2.2.3)

@@ -20,7 +20,9 @@
 #define JH_SUBSEQ_SHIFT 11            // log2 of the bits per speculative sub-sequence (one thread each): 2048 is the measured
                                       // best for ordinary images; JhDecodeWork.sub_shift is what the kernels use (dense data: 12)
 #define JH_SUBSEQ_SHIFT_DENSE 12
+#ifndef JH_CHAIN_MAX
 #define JH_CHAIN_MAX 16               // steps a speculative chain may walk before it is cut
+#endif
 #define JH_SEQ_OWN (256 - JH_CHAIN_MAX)   // sub-sequences owned by one workgroup (the rest are ghosts)
 // chains workgroup b covers sub-sequences [b * OWN, b * OWN + 256) and EMITS the entry records of
 // [b * OWN + (b ? JH_CHAIN_MAX : 0), b * OWN + 256): the first JH_CHAIN_MAX belong to its predecessor
@@ -35,14 +37,32 @@
 //   bit 15 = 1 (fast[] only): the code is longer than JH_LUT_BITS bits; the low bits name the
 //               second-level table indexed by the next 6 bits, JH_LUT_SEARCH = canonical search,
 //               JH_LUT_INVALID = no code matches
+// pair[] (AC tables; 0 = none), same index as fast[]: the window's first symbol AND the one behind it, where the
+// second code also lies inside the JH_LUT_BITS bits of the index (the metric stream averages 5.1 bits a symbol: two
+// in three look-ups resolve a pair, and the decode loops take a third fewer trips):
+//   bits 11..15 total bits of both symbols (codes + magnitude bits, <= 31)
+//   bits  4..10 run1 + 1 + run2: from the zig-zag index in front of the first symbol to the coefficient of the second
+//               (run2 = 63 for EOB, so that the sum says "block complete" like the single entry does)
+//   bits  0..3  category of the second symbol
+// A pair is only built behind a first symbol that is not EOB; the decoder uses it only if the first symbol does not
+// complete the block by itself (zero run to coefficient 63 and beyond in damaged data).
+// DC tables use neither pair[] nor sub[] (their rare long codes take the canonical search): the kernels' LDS copy
+// of a DC table ends in front of sub[] (JH_LUT_DC_BYTES) -- that is what lets three workgroups of k_huff_write share
+// a CU's LDS.
 struct JhHuffLut {
 	uint16_t fast[1 << JH_LUT_BITS];
-	uint16_t sub[JH_SUB_TABLES][64];
 	uint32_t limit[17];               // limit[l] = (maxcode[l] + 1) << (16 - l), non-decreasing; l = 1..16
 	int32_t  offs[17];                // valptr[l] - mincode[l]
 	uint8_t  huffval[256];
-	uint8_t  pad[8];                  // sizeof is a multiple of 16 (table offsets are kept in units of 16)
+	uint8_t  pad[8];                  // the short form and the whole are multiples of 16 (table offsets are kept in units of 16)
+	uint16_t sub[JH_SUB_TABLES][64];
+	uint16_t pair[1 << JH_LUT_BITS];
 };
+#define JH_LUT_DC_BYTES 2448u         // offsetof(JhHuffLut, sub)
+#define JH_LUT_PAIR_OFF 3472u         // offsetof(JhHuffLut, pair)
+#define JH_PAIR_TOTAL(p) ((p) >> 11)
+#define JH_PAIR_ADV(p) (((p) >> 4) & 127u)
+#define JH_PAIR_CAT2(p) ((p) & 15u)
 
 struct JhHuffEnc {                    // one Huffman table, encoder view (EHUFCO/EHUFSI, huffman.c:118-148)
 	uint32_t code[256];               // (code << 8) | size ; size == 0: symbol absent

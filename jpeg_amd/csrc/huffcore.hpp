@@ -18,6 +18,7 @@
 #include "kernels.hpp"
 
 struct DecTables {                    // workgroup-shared decode context (LDS)
+	uint32_t slot_off[9];             // byte offset of every table of the frame inside the LDS copy (DC tables are short there)
 	// per block of the MCU: (DC table offset / 16) | (AC table offset / 16) << 12 | component << 24
 	uint32_t info[JH_MAX_MCU_BLOCKS];
 	// the same, unpacked for the hot loop (one 16-byte read): x = byte offset of the DC table inside the
@@ -126,10 +127,20 @@ __device__ __forceinline__ int extend_sign(unsigned extra, int cat)
 	return (int)extra - ((extra >> ((cat - 1) & 31)) ? 0 : (1 << cat) - 1);
 }
 
+// fast[] and pair[] entry of the window in one word (pair in the high half): two 16-bit LDS reads off one address.
+// Of a DC table only the low half means anything: its LDS copy has no pair[] (the read lands in the next table).
+__device__ __forceinline__ unsigned lut_lookup(const unsigned char *tab, uint32_t win)
+{
+	const unsigned char *p = tab + ((win >> (32 - JH_LUT_BITS)) << 1);
+	return (unsigned)*reinterpret_cast<const uint16_t *>(p) |
+	       ((unsigned)*reinterpret_cast<const uint16_t *>(p + JH_LUT_PAIR_OFF) << 16);
+}
+
 // resolves a first-level entry with bit 15 set: second-level table, canonical search, or 0 = no code
 __device__ __forceinline__ unsigned long_code(const unsigned char *tab, unsigned e, uint32_t win, bool isdc)
 {
 	const JhHuffLut *L = reinterpret_cast<const JhHuffLut *>(tab);
+	e &= 0xffffu;                                          // (lut_lookup: the high half belongs to pair[])
 	if (e == JH_LUT_INVALID) {
 		return 0;
 	}
@@ -182,6 +193,9 @@ __device__ __forceinline__ void decode_span_segmented(DecState &st, const uint32
 	uint32_t seg_end = min(seg_start[st.seg + 1] * 8u, total_bits);
 	uint32_t pos = st.pos;
 	int c = st.c, z = st.z, nb = st.nb;
+	// a second symbol resolved by the same look-up starts less than JH_LUT_BITS bits behind the first: below this
+	// position it starts before `stop`, i.e. belongs to this span too
+	const uint32_t stop_pair = stop > (uint32_t)JH_LUT_BITS ? stop - (uint32_t)JH_LUT_BITS + 1u : 0u;
 	bool primed = false;
 	int cn = 0;
 	uint4 ent_n = make_uint4(0, 0, 0, 0);
@@ -212,7 +226,7 @@ __device__ __forceinline__ void decode_span_segmented(DecState &st, const uint32
 				S.open(cur, wi, w0, w1, w2);
 				win = bit_window(w0, w1, pos);
 				tab = z == 0 ? ent.x : tac;
-				e = *reinterpret_cast<const uint16_t *>(luts + tab + ((win >> (32 - JH_LUT_BITS)) << 1));
+				e = lut_lookup(luts + tab, win);
 				primed = true;
 			}
 		}
@@ -226,9 +240,14 @@ __device__ __forceinline__ void decode_span_segmented(DecState &st, const uint32
 				fs = ok ? fs : pos;            // no code matches: the careful path ends the segment
 			}
 			if (ok) {
-				const int total = (int)(e >> 10), run = (int)((e >> 4) & 63u), cat = (int)(e & 15u);
+				const int total1 = (int)((e >> 10) & 31u), run = (int)((e >> 4) & 63u), cat = (int)(e & 15u);
+				// the symbol behind it as well, if the table has resolved it (JhHuffLut), the first one leaves the
+				// block open, and the second one still starts inside this sub-sequence
+				const unsigned pr = e >> 16;
+				const bool two = pr != 0 && !isdc && z + run < 63 && pos < stop_pair;
+				const int total = two ? (int)JH_PAIR_TOTAL(pr) : total1;
 				const uint32_t npos = pos + (uint32_t)total;
-				const int k = z + run;                              // zero run (coeffs.c:246)
+				const int k = z + (two ? (int)JH_PAIR_ADV(pr) : run);   // zero run(s) (coeffs.c:246)
 				const bool done = k >= 63;
 				// the next symbol: its table, its window, its look-up
 				const uint32_t tabn = done ? ent_n.x : tac;
@@ -238,10 +257,10 @@ __device__ __forceinline__ void decode_span_segmented(DecState &st, const uint32
 				w1 = cross ? w2 : w1;
 				wi = nwi;
 				const uint32_t nwin = bit_window(w0, w1, npos);
-				const unsigned en = *reinterpret_cast<const uint16_t *>(luts + tabn + ((nwin >> (32 - JH_LUT_BITS)) << 1));
+				const unsigned en = lut_lookup(luts + tabn, nwin);
 				w2 = S.next(cur, cross, w2);
-				// the current symbol's value: only the DC differences are summed here
-				const unsigned extra = __builtin_amdgcn_ubfe(win, 32u - (unsigned)total, (unsigned)cat);
+				// the current symbol's value: only the DC differences are summed here (a DC symbol is never one of two)
+				const unsigned extra = __builtin_amdgcn_ubfe(win, 32u - (unsigned)total1, (unsigned)cat);
 				const int val = extend_sign(extra, cat);
 				atomicAdd(reinterpret_cast<int *>(reinterpret_cast<char *>(dcs) + dca), isdc ? val : 0);
 				// next zig-zag index / next block
@@ -361,6 +380,9 @@ __device__ __forceinline__ void decode_span_plain(DecState &st, const uint32_t s
 	uint32_t seg_end = min(seg_start[st.seg + 1] * 8u, total_bits);
 	uint32_t pos = st.pos;
 	int c = st.c, z = st.z, nb = st.nb;
+	// a second symbol resolved by the same look-up starts less than JH_LUT_BITS bits behind the first: below this
+	// position it starts before `stop`, i.e. belongs to this span too
+	const uint32_t stop_pair = stop > (uint32_t)JH_LUT_BITS ? stop - (uint32_t)JH_LUT_BITS + 1u : 0u;
 
 	for (;;) {
 		// ------------------------------------------------------------------------------ fast
@@ -376,7 +398,7 @@ __device__ __forceinline__ void decode_span_plain(DecState &st, const uint32_t s
 			S.open(cur, wi, w0, w1, w2);
 			uint32_t win = bit_window(w0, w1, pos);
 			uint32_t tab = z == 0 ? ent.x : tac;
-			unsigned e = *reinterpret_cast<const uint16_t *>(luts + tab + ((win >> (32 - JH_LUT_BITS)) << 1));
+			unsigned e = lut_lookup(luts + tab, win);
 			do {
 				const bool isdc = z == 0;
 				if (e & 0x8000u) {
@@ -385,22 +407,27 @@ __device__ __forceinline__ void decode_span_plain(DecState &st, const uint32_t s
 						break;                 // no code matches: the careful path ends the segment
 					}
 				}
-				const int total = (int)(e >> 10), run = (int)((e >> 4) & 63u), cat = (int)(e & 15u);
+				const int total1 = (int)((e >> 10) & 31u), run = (int)((e >> 4) & 63u), cat = (int)(e & 15u);
+				// the symbol behind it as well, if the table has resolved it (JhHuffLut), the first one leaves the
+				// block open, and the second one still starts inside this sub-sequence
+				const unsigned pr = e >> 16;
+				const bool two = pr != 0 && !isdc && z + run < 63 && pos < stop_pair;
+				const int total = two ? (int)JH_PAIR_TOTAL(pr) : total1;
 				const uint32_t npos = pos + (uint32_t)total;
-				const int k = z + run;                              // zero run (coeffs.c:246)
+				const int k = z + (two ? (int)JH_PAIR_ADV(pr) : run);   // zero run(s) (coeffs.c:246)
 				const bool done = k >= 63;
 				// the next symbol: its table, its window, its look-up
 				const uint32_t tabn = done ? ent_n.x : tac;
 				const uint32_t nwi = npos >> 5;
-				const bool cross = nwi != wi;                       // a symbol has at most 31 bits
+				const bool cross = nwi != wi;                       // one or two symbols: at most 31 bits
 				w0 = cross ? w1 : w0;
 				w1 = cross ? w2 : w1;
 				wi = nwi;
 				const uint32_t nwin = bit_window(w0, w1, npos);
-				const unsigned en = *reinterpret_cast<const uint16_t *>(luts + tabn + ((nwin >> (32 - JH_LUT_BITS)) << 1));
+				const unsigned en = lut_lookup(luts + tabn, nwin);
 				w2 = S.next(cur, cross, w2);
-				// the current symbol's value
-				const unsigned extra = __builtin_amdgcn_ubfe(win, 32u - (unsigned)total, (unsigned)cat);
+				// the current symbol's value (a DC symbol is never one of two)
+				const unsigned extra = __builtin_amdgcn_ubfe(win, 32u - (unsigned)total1, (unsigned)cat);
 				int val = extend_sign(extra, cat);
 				int *acc = reinterpret_cast<int *>(reinterpret_cast<char *>(dcs) + dca);
 				if (WRITE) {
@@ -537,24 +564,38 @@ __device__ __forceinline__ uint32_t find_segment(const uint32_t *seg_start, uint
 	return lo;
 }
 
+// bytes the tables of a frame take in LDS: AC tables whole, DC tables in their short form (host: api.hip sizes the
+// kernels' LDS with the same rule)
 __device__ __forceinline__ void load_tables(const JhDecodeWork &w, const JhDecFrame &fr, unsigned char *luts, DecTables *tb,
                                             const JhGeom &g, int zunit)
 {
-	const uint32_t *src = reinterpret_cast<const uint32_t *>(w.luts + fr.lut_off);
-	uint32_t *dst = reinterpret_cast<uint32_t *>(luts);
-	const int nw = (int)(fr.n_lut * sizeof(JhHuffLut) / 4);
-	for (int i = threadIdx.x; i < nw; i += blockDim.x) {
-		dst[i] = src[i];
+	// read through the global pointer: indexing the by-value copy would put it in scratch
+	const JhDecFrame *gf = w.frames + blockIdx.y;
+	if (threadIdx.x == 0) {
+		uint32_t off = 0;
+		for (uint32_t s = 0; s < fr.n_lut && s < 8u; ++s) {
+			bool isdc = false;
+			for (int b = 0; b < g.B; ++b) {
+				isdc = isdc || gf->blk_dc[b] == s;
+			}
+			tb->slot_off[s] = off;
+			off += isdc ? JH_LUT_DC_BYTES : (uint32_t)sizeof(JhHuffLut);
+		}
+		tb->slot_off[fr.n_lut < 8u ? fr.n_lut : 8u] = off;
+	}
+	__syncthreads();
+	for (uint32_t s = 0; s < fr.n_lut && s < 8u; ++s) {
+		const uint32_t *src = reinterpret_cast<const uint32_t *>(w.luts + fr.lut_off + s);
+		uint32_t *dst = reinterpret_cast<uint32_t *>(luts + tb->slot_off[s]);
+		const int nw = (int)((tb->slot_off[s + 1] - tb->slot_off[s]) / 4);
+		for (int i = threadIdx.x; i < nw; i += blockDim.x) {
+			dst[i] = src[i];
+		}
 	}
 	if (threadIdx.x < JH_MAX_MCU_BLOCKS) {
-		// read through the global pointer: indexing the by-value copy would put it in scratch
-		const JhDecFrame *gf = w.frames + blockIdx.y;
-		const uint32_t unit = (uint32_t)(sizeof(JhHuffLut) / 16);
-		tb->info[threadIdx.x] = gf->blk_dc[threadIdx.x] * unit | (gf->blk_ac[threadIdx.x] * unit) << 12 |
-		                        (uint32_t)g.blk_comp[threadIdx.x] << 24;
-		tb->ent[threadIdx.x] = make_uint4(gf->blk_dc[threadIdx.x] * (uint32_t)sizeof(JhHuffLut),
-		                                  gf->blk_ac[threadIdx.x] * (uint32_t)sizeof(JhHuffLut),
-		                                  (uint32_t)g.blk_comp[threadIdx.x] * (uint32_t)zunit,
+		const uint32_t odc = tb->slot_off[gf->blk_dc[threadIdx.x] & 7], oac = tb->slot_off[gf->blk_ac[threadIdx.x] & 7];
+		tb->info[threadIdx.x] = (odc >> 4) | (oac >> 4) << 12 | (uint32_t)g.blk_comp[threadIdx.x] << 24;
+		tb->ent[threadIdx.x] = make_uint4(odc, oac, (uint32_t)g.blk_comp[threadIdx.x] * (uint32_t)zunit,
 		                                  (int)threadIdx.x + 1 >= g.B ? 0u : threadIdx.x + 1u);
 	}
 	__syncthreads();

@@ -514,7 +514,7 @@ __global__ __launch_bounds__(WR_THREADS) void k_huff_write(const HuffArgs a)
 {
 	extern __shared__ __align__(16) unsigned char smem[];
 	unsigned char *luts = smem;
-	int4 *bufs = reinterpret_cast<int4 *>(smem + sizeof(JhHuffLut) * a.w.max_luts);
+	int4 *bufs = reinterpret_cast<int4 *>(smem + a.w.lut_bytes);
 	__shared__ DecTables tb;
 	__shared__ int dcs_all[JH_MAX_COMP][WR_THREADS];
 
@@ -609,7 +609,7 @@ __global__ __launch_bounds__(WR_THREADS) void k_huff_write(const HuffArgs a)
 				S.open(cur, wi, w0, w1, w2);
 				win = bit_window(w0, w1, pos);
 				tab = z == 0 ? ent.x : tac;
-				e = *reinterpret_cast<const uint16_t *>(luts + tab + ((win >> (32 - JH_LUT_BITS)) << 1));
+				e = lut_lookup(luts + tab, win);
 				fl |= F_PRIMED;
 			}
 		}
@@ -619,9 +619,16 @@ __global__ __launch_bounds__(WR_THREADS) void k_huff_write(const HuffArgs a)
 		}
 		if (fast) {
 			const bool isdc = z == 0;
-			const int total = (int)(e >> 10), run = (int)((e >> 4) & 63u), cat = (int)(e & 15u);
+			const int total1 = (int)((e >> 10) & 31u), run = (int)((e >> 4) & 63u), cat = (int)(e & 15u);
+			// The symbol behind it as well, if the table has resolved it (JhHuffLut) and the first one leaves the block
+			// open: two coefficients per trip.  (A DC symbol is never one of two; a thread runs on to the end of the
+			// block it is in, so a pair never has to stop at the sub-sequence's end.)
+			const unsigned pr = e >> 16;
+			const int k1 = z + run;                                 // zero run (coeffs.c:246)
+			const bool two = pr != 0 && !isdc && k1 < 63;
+			const int total = two ? (int)JH_PAIR_TOTAL(pr) : total1;
 			const uint32_t npos = pos + (uint32_t)total;
-			const int k = z + run;                                  // zero run (coeffs.c:246)
+			const int k = two ? z + (int)JH_PAIR_ADV(pr) : k1;
 			const bool done = k >= 63;
 			// the next symbol: its table, its window, its look-up
 			const uint32_t tabn = done ? ent_n.x : tac;
@@ -631,10 +638,10 @@ __global__ __launch_bounds__(WR_THREADS) void k_huff_write(const HuffArgs a)
 			w1 = cross ? w2 : w1;
 			wi = nwi;
 			const uint32_t nwin = bit_window(w0, w1, npos);
-			const unsigned en = *reinterpret_cast<const uint16_t *>(luts + tabn + ((nwin >> (32 - JH_LUT_BITS)) << 1));
+			const unsigned en = lut_lookup(luts + tabn, nwin);
 			w2 = S.next(cur, cross, w2);
-			// the current symbol's value; DC un-prediction (decoder.c:351-355)
-			const unsigned extra = __builtin_amdgcn_ubfe(win, 32u - (unsigned)total, (unsigned)cat);
+			// the first symbol's value; DC un-prediction (decoder.c:351-355)
+			const unsigned extra = __builtin_amdgcn_ubfe(win, 32u - (unsigned)total1, (unsigned)cat);
 			int val = extend_sign(extra, cat);
 			const int old = atomicAdd(reinterpret_cast<int *>(reinterpret_cast<char *>(dcs) + comp), isdc ? val : 0);
 			val += isdc ? old : 0;
@@ -642,8 +649,15 @@ __global__ __launch_bounds__(WR_THREADS) void k_huff_write(const HuffArgs a)
 			if (WIDE) {
 				wide |= isdc ? (val + 32768) : 0;                   // bit 16 and up, or negative: not an int16
 			}
-			// coefficient k of the block in progress; EOB and ZRL carry a zero, a run past the end (k > 63) stores one
-			mybuf[(min(k, 63) + rot) & 63] = (int16_t)(k < 64 ? val : 0);
+			// coefficient k1 of the block in progress; EOB and ZRL carry a zero, a run past the end (k1 > 63) stores one
+			mybuf[(min(k1, 63) + rot) & 63] = (int16_t)(k1 < 64 ? val : 0);
+			if (two) {
+				// the second symbol's: its magnitude bits are the last cat2 of the pair's bits
+				const int cat2 = (int)JH_PAIR_CAT2(pr);
+				const unsigned extra2 = __builtin_amdgcn_ubfe(win, 32u - (unsigned)total, (unsigned)cat2);
+				const int val2 = extend_sign(extra2, cat2);
+				mybuf[(min(k, 63) + rot) & 63] = (int16_t)(k < 64 ? val2 : 0);
+			}
 			z = done ? 0 : k + 1;
 			fin = done;
 			fblk = (done && (fl & F_OWN) && (unsigned)blk < (unsigned)nblk) ? blk : -1;
@@ -911,7 +925,7 @@ int jh_launch_huff_decode(const JhDecodeWork &w, const JhGeom &g, hipStream_t s,
 		return -1;
 	}
 	// one launch configuration for the batch: LDS for the largest table set of any frame
-	const size_t lds = sizeof(JhHuffLut) * (size_t)w.max_luts + (size_t)WR_THREADS * 128;
+	const size_t lds = (size_t)w.lut_bytes + (size_t)WR_THREADS * 128;
 	const bool wide = g.P > 12;
 	void (*wr)(const HuffArgs) = w.rm.mode ? (wide ? k_huff_write<true, true> : k_huff_write<true, false>)
 	                                       : (wide ? k_huff_write<false, true> : k_huff_write<false, false>);

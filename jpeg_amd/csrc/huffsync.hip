@@ -988,7 +988,7 @@ int jh_launch_huff_sync(const JhDecodeWork &w, const JhGeom &g, hipStream_t s, c
 	a.w = w;
 	a.g = g;
 	a.round = 0;
-	const size_t lds = sizeof(JhHuffLut) * (size_t)w.max_luts;
+	const size_t lds = (size_t)w.lut_bytes;
 	const unsigned nwg = jh_num_chain_wgs(w.max_subs);
 	const unsigned nblk = (w.max_subs + 255u) / 256u;
 	JH_T_BEGIN(th, "k_huff_chains", s);

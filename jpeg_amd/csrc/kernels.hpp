@@ -93,7 +93,8 @@ struct JhDecodeWork {             // device pointers of one decoder batch
 	int nframes;
 	uint32_t max_chunks;          // per frame (grid size)
 	uint32_t max_subs;            // per frame (grid size)
-	uint32_t max_luts;            // Huffman tables of the frame that uses most (LDS size)
+	uint32_t max_luts;            // Huffman tables of the frame that uses most
+	uint32_t lut_bytes;           // LDS the tables of the frame that needs most take (DC tables in their short form), 16-aligned
 	uint32_t sub_shift;           // log2 of the bits per speculative sub-sequence (one thread each): 11, or 12 for dense data
 	int debug;                    // bit 0: force repairs, bit 1: force the serial walk (tests)
 	int segmented;                // a frame of the batch announces restart intervals (DRI): which form of the decode loop the
