@@ -361,6 +361,29 @@ int jpeg_hip_adapt_tables(int device, const jpeg_hip_frame_desc *frame, const jp
                           jpeg_hip_htable dc[4], jpeg_hip_htable ac[4],
                           const int32_t *const coef[JPEG_HIP_MAX_COMP]);
 
+/* ---- the stages one by one ---------------------------------------------------------------------
+ * SURVEY.md section 8b's table, row by row: the reference's per-stage functions on `struct context` / `struct frame`,
+ * on the buffers they work on (host pointers, one call = upload + one kernel + download; the fused kernels of the
+ * batch objects are the fast path, these are the drop-in and the parity path for the FLOAT stage boundaries).
+ * integration/ref_glue.c (-DGLUE_STAGES) defines dequantize(), inverse_dct(), forward_dct(), quantize(),
+ * frame_to_rgb() and frame_to_ycc() with the reference's signatures on top of them; conv_blocks_to_frame() /
+ * conv_frame_to_blocks() (imgproc.h:18-20) and the two transform_*() (frame.c:38-132) only move and copy samples and
+ * stay the reference's own there.
+ *   dequantize_blocks   dequantize() / dequantize_block()  imgproc.c:10-19,32-56: out = (float)(coef * Q), Q = qtable[Tq].Q
+ *   quantize_blocks     quantize()   / quantize_block()    imgproc.c:21-30,58-82: out = (int32)roundf(in / Q)
+ *   inverse_dct_blocks  inverse_dct()                      imgproc.c:172-200:     idct, then + 2^(P-1), in place
+ *   forward_dct_blocks  forward_dct()                      imgproc.c:202-230:     - 2^(P-1), then fdct, in place
+ *     (arrays of nblocks blocks of 64, raster order inside a block: component[].int_buffer / flt_buffer, coeffs.h:9-16)
+ *   frame_to_rgb        frame.c:188-244 (3 or 4 components; 1: nothing to do)   on frame->data: size_y rows of size_x
+ *   frame_to_ycc        frame.c:154-186 (3 components; 1: nothing to do)        pixels of `components` floats, only
+ *                                                                               x < X, y < Y are converted */
+int jpeg_hip_dequantize_blocks(int device, size_t nblocks, const int32_t *coef, const uint16_t Q[64], float *out);
+int jpeg_hip_quantize_blocks(int device, size_t nblocks, const float *in, const uint16_t Q[64], int32_t *out);
+int jpeg_hip_inverse_dct_blocks(int device, size_t nblocks, float *blocks, int P);
+int jpeg_hip_forward_dct_blocks(int device, size_t nblocks, float *blocks, int P);
+int jpeg_hip_frame_to_rgb(int device, float *data, int components, int X, int Y, size_t size_x, size_t size_y, int P);
+int jpeg_hip_frame_to_ycc(int device, float *data, int components, int X, int Y, size_t size_x, size_t size_y, int P);
+
 /* ---- single-image drop-ins for the reference's top-level entry points ------------------------
  * Same argument meaning and error behaviour as the functions they replace; the pixel and entropy
  * work runs on the GPU, marker parsing/production and PPM/PGM I/O on the host. */

@@ -21,6 +21,17 @@
  *
  * Compile with -DGLUE_DECODER or -DGLUE_ENCODER (struct scan and the loops differ per program), with the
  * reference's directory on the include path.  This file holds no code of the reference.
+ *
+ * -DGLUE_STAGES is the other way to adopt the library, stage by stage (SURVEY.md section 8b's table): the reference
+ * keeps ALL of its drivers and loops -- read_ecs(), epilogue(), prologue(), write_ecs() included -- and only its
+ * arithmetic stages are replaced, under their own names and signatures:
+ *
+ *     int dequantize(struct context *)      imgproc.h:8      int quantize(struct context *)       imgproc.h:10
+ *     int inverse_dct(struct context *)     imgproc.h:14     int forward_dct(struct context *)    imgproc.h:16
+ *     int frame_to_rgb(struct frame *)      frame.h:21       int frame_to_ycc(struct frame *)     frame.h:33
+ *
+ * (weakened in imgproc.o / frame.o by the recipe; conv_blocks_to_frame(), conv_frame_to_blocks() and the two
+ * transform_*() only move samples and stay the reference's own).  oracle/_ref/decoder_stages / encoder_stages.
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -36,6 +47,7 @@
 #define JPEG_HIP_DEVICE 0
 #endif
 
+#if defined(GLUE_DECODER) || defined(GLUE_ENCODER)
 /* struct scan is private to decoder.c:186-195 / encoder.c:318-327 (the same three members in both) */
 struct scan {
 	uint8_t Ns;
@@ -141,6 +153,8 @@ static void describe_tables(struct context *c, jpeg_hip_htable dc[4], jpeg_hip_h
 		flatten_htable(&c->htable[1][t], &ac[t]);
 	}
 }
+
+#endif /* GLUE_DECODER || GLUE_ENCODER */
 
 #ifdef GLUE_DECODER
 
@@ -400,3 +414,69 @@ int write_ecs(FILE *stream, struct context *context, struct scan *scan)
 }
 
 #endif /* GLUE_ENCODER */
+
+#ifdef GLUE_STAGES
+/* ---- the arithmetic stages, one GPU call per component (or per frame) each ------------------------------ */
+
+int dequantize(struct context *context)                        /* imgproc.c:32-56 */
+{
+	for (int i = 0; i < 256; ++i) {
+		struct component *c = &context->component[i];
+		if (c->int_buffer != NULL) {
+			int err = jpeg_hip_dequantize_blocks(JPEG_HIP_DEVICE, c->b_x * c->b_y, (const int32_t *)c->int_buffer,
+			                                     context->qtable[c->Tq].Q, (float *)c->flt_buffer);
+			RETURN_IF(err);
+		}
+	}
+	return RET_SUCCESS;
+}
+
+int quantize(struct context *context)                          /* imgproc.c:58-82 */
+{
+	for (int i = 0; i < 256; ++i) {
+		struct component *c = &context->component[i];
+		if (c->int_buffer != NULL) {
+			int err = jpeg_hip_quantize_blocks(JPEG_HIP_DEVICE, c->b_x * c->b_y, (const float *)c->flt_buffer,
+			                                   context->qtable[c->Tq].Q, (int32_t *)c->int_buffer);
+			RETURN_IF(err);
+		}
+	}
+	return RET_SUCCESS;
+}
+
+int inverse_dct(struct context *context)                       /* imgproc.c:172-200 */
+{
+	for (int i = 0; i < 256; ++i) {
+		struct component *c = &context->component[i];
+		if (c->int_buffer != NULL) {
+			int err = jpeg_hip_inverse_dct_blocks(JPEG_HIP_DEVICE, c->b_x * c->b_y, (float *)c->flt_buffer, context->P);
+			RETURN_IF(err);
+		}
+	}
+	return RET_SUCCESS;
+}
+
+int forward_dct(struct context *context)                       /* imgproc.c:202-230 */
+{
+	for (int i = 0; i < 256; ++i) {
+		struct component *c = &context->component[i];
+		if (c->int_buffer != NULL) {
+			int err = jpeg_hip_forward_dct_blocks(JPEG_HIP_DEVICE, c->b_x * c->b_y, (float *)c->flt_buffer, context->P);
+			RETURN_IF(err);
+		}
+	}
+	return RET_SUCCESS;
+}
+
+int frame_to_rgb(struct frame *frame)                          /* frame.c:188-244 */
+{
+	return jpeg_hip_frame_to_rgb(JPEG_HIP_DEVICE, frame->data, frame->components, frame->X, frame->Y,
+	                             frame->size_x, frame->size_y, frame->precision);
+}
+
+int frame_to_ycc(struct frame *frame)                          /* frame.c:154-186 */
+{
+	return jpeg_hip_frame_to_ycc(JPEG_HIP_DEVICE, frame->data, frame->components, frame->X, frame->Y,
+	                             frame->size_x, frame->size_y, frame->precision);
+}
+#endif /* GLUE_STAGES */

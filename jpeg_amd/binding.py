@@ -46,6 +46,8 @@ EXPORTS = [
     "jpeg_hip_selftest_ycc8",
     "jpeg_hip_streams_create", "jpeg_hip_streams_destroy",
     "jpeg_hip_decoder_set_float_tap", "jpeg_hip_encoder_set_float_tap",
+    "jpeg_hip_dequantize_blocks", "jpeg_hip_quantize_blocks", "jpeg_hip_inverse_dct_blocks", "jpeg_hip_forward_dct_blocks",
+    "jpeg_hip_frame_to_rgb", "jpeg_hip_frame_to_ycc",
 ]
 
 
@@ -169,6 +171,12 @@ def lib():
         L.jpeg_hip_streams_create.argtypes = [C.c_int, C.c_int, vp, C.c_int, C.POINTER(vp)]
         L.jpeg_hip_streams_destroy.argtypes = [C.c_int, C.c_int, C.POINTER(vp)]
         L.jpeg_hip_streams_destroy.restype = None
+        L.jpeg_hip_dequantize_blocks.argtypes = [C.c_int, sz, vp, vp, vp]
+        L.jpeg_hip_quantize_blocks.argtypes = [C.c_int, sz, vp, vp, vp]
+        L.jpeg_hip_inverse_dct_blocks.argtypes = [C.c_int, sz, vp, C.c_int]
+        L.jpeg_hip_forward_dct_blocks.argtypes = [C.c_int, sz, vp, C.c_int]
+        L.jpeg_hip_frame_to_rgb.argtypes = [C.c_int, vp, C.c_int, C.c_int, C.c_int, sz, sz, C.c_int]
+        L.jpeg_hip_frame_to_ycc.argtypes = [C.c_int, vp, C.c_int, C.c_int, C.c_int, sz, sz, C.c_int]
         for fn in (L.jpeg_hip_decoder_set_float_tap, L.jpeg_hip_encoder_set_float_tap):
             fn.argtypes = [vp, vp]
             fn.restype = None

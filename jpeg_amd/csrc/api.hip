@@ -2181,6 +2181,119 @@ extern "C" int jpeg_hip_encoder_get_timing(jpeg_hip_encoder *enc, const char **n
 	return enc->timer.collect(names, ms, cap);
 }
 
+// ======================================================================================= the stages one by one
+//
+// dequantize / quantize / inverse_dct / forward_dct (imgproc.h:8-16) and frame_to_rgb / frame_to_ycc (frame.h:21,33) on the
+// reference's own buffers, one kernel each: host pointers in and out, synchronous, like the other stage-level calls.
+// integration/ref_glue.c (-DGLUE_STAGES) puts them behind the reference's function names.
+
+struct StageBuf {                      // device copies of a stage call's arrays, freed when the call returns
+	void *p[3] = {nullptr, nullptr, nullptr};
+	~StageBuf()
+	{
+		for (void *q : p) {
+			hipFree(q);
+		}
+	}
+};
+
+static int stage_blocks(int device, int what, size_t nblocks, const void *in, size_t in_elem, const uint16_t *Q,
+                        void *out, size_t out_elem, int P)
+{
+	int err = require_device(device);
+	if (err) {
+		return err;
+	}
+	if ((!in || !out) && nblocks) {
+		return RET_FAILURE_LOGIC_ERROR;
+	}
+	if (nblocks == 0) {
+		return RET_SUCCESS;
+	}
+	if (P < 1 || P > 16) {
+		return RET_FAILURE_FILE_UNSUPPORTED;
+	}
+	const size_t n = nblocks * 64;
+	StageBuf b;
+	const bool inplace = what == JH_STAGE_IDCT || what == JH_STAGE_FDCT;
+	HIPCHK(hipMalloc(&b.p[0], n * in_elem));
+	HIPCHK(hipMemcpy(b.p[0], in, n * in_elem, hipMemcpyHostToDevice));
+	if (!inplace) {
+		if (!Q) {
+			return RET_FAILURE_LOGIC_ERROR;
+		}
+		HIPCHK(hipMalloc(&b.p[1], 64 * sizeof(uint16_t)));
+		HIPCHK(hipMemcpy(b.p[1], Q, 64 * sizeof(uint16_t), hipMemcpyHostToDevice));
+		HIPCHK(hipMalloc(&b.p[2], n * out_elem));
+	}
+	if (jh_launch_stage(what, b.p[0], b.p[1], b.p[2], inplace ? nblocks : n, P, 0, 0, 0, nullptr)) {
+		return RET_FAILURE_LOGIC_ERROR;
+	}
+	HIPCHK(hipMemcpy(out, inplace ? b.p[0] : b.p[2], n * out_elem, hipMemcpyDeviceToHost));
+	return RET_SUCCESS;
+}
+
+extern "C" int jpeg_hip_dequantize_blocks(int device, size_t nblocks, const int32_t *coef, const uint16_t Q[64], float *out)
+{
+	return stage_blocks(device, JH_STAGE_DEQUANTIZE, nblocks, coef, sizeof(int32_t), Q, out, sizeof(float), 8);
+}
+
+extern "C" int jpeg_hip_quantize_blocks(int device, size_t nblocks, const float *in, const uint16_t Q[64], int32_t *out)
+{
+	if (Q) {
+		for (int i = 0; i < 64; ++i) {
+			if (Q[i] == 0) {
+				return RET_FAILURE_FILE_UNSUPPORTED;           // quantize_block() would divide by zero
+			}
+		}
+	}
+	return stage_blocks(device, JH_STAGE_QUANTIZE, nblocks, in, sizeof(float), Q, out, sizeof(int32_t), 8);
+}
+
+extern "C" int jpeg_hip_inverse_dct_blocks(int device, size_t nblocks, float *blocks, int P)
+{
+	return stage_blocks(device, JH_STAGE_IDCT, nblocks, blocks, sizeof(float), nullptr, blocks, sizeof(float), P);
+}
+
+extern "C" int jpeg_hip_forward_dct_blocks(int device, size_t nblocks, float *blocks, int P)
+{
+	return stage_blocks(device, JH_STAGE_FDCT, nblocks, blocks, sizeof(float), nullptr, blocks, sizeof(float), P);
+}
+
+static int stage_colour(int device, int what, float *data, int components, int X, int Y, size_t size_x, size_t size_y, int P)
+{
+	int err = require_device(device);
+	if (err) {
+		return err;
+	}
+	if (components == 1) {
+		return RET_SUCCESS;                                    // nothing to do (frame.c:176-178, 236-238)
+	}
+	const bool ok = what == JH_STAGE_TO_RGB ? (components == 3 || components == 4) : components == 3;
+	if (!data || !ok || X <= 0 || Y <= 0 || (size_t)X > size_x || (size_t)Y > size_y || P < 1 || P > 16) {
+		return RET_FAILURE_LOGIC_ERROR;                        // (the reference abort()s on other component counts)
+	}
+	const size_t bytes = size_x * size_y * (size_t)components * sizeof(float);
+	StageBuf b;
+	HIPCHK(hipMalloc(&b.p[0], bytes));
+	HIPCHK(hipMemcpy(b.p[0], data, bytes, hipMemcpyHostToDevice));
+	if (jh_launch_stage(what, b.p[0], (const void *)(size_t)P, nullptr, (size_t)X * Y, components, X, Y, size_x, nullptr)) {
+		return RET_FAILURE_LOGIC_ERROR;
+	}
+	HIPCHK(hipMemcpy(data, b.p[0], bytes, hipMemcpyDeviceToHost));
+	return RET_SUCCESS;
+}
+
+extern "C" int jpeg_hip_frame_to_rgb(int device, float *data, int components, int X, int Y, size_t size_x, size_t size_y, int P)
+{
+	return stage_colour(device, JH_STAGE_TO_RGB, data, components, X, Y, size_x, size_y, P);
+}
+
+extern "C" int jpeg_hip_frame_to_ycc(int device, float *data, int components, int X, int Y, size_t size_x, size_t size_y, int P)
+{
+	return stage_colour(device, JH_STAGE_TO_YCC, data, components, X, Y, size_x, size_y, P);
+}
+
 // ======================================================================================= self-test
 
 extern "C" int jpeg_hip_selftest_divide(int device, int ties_per_divisor, unsigned seed, unsigned long long out[3])

@@ -127,6 +127,11 @@ int jh_launch_encode_pixels(const JhGeom &g, int nframes, const void *in, size_t
 // crosses -- decode: frame->data behind frame_to_rgb (frame.c:188-244), [frame][Y][X][1 or 3]; encode: the component
 // planes behind transform_frame_to_components (frame.c:84-132), [frame][planes of by*8 x bx*8] -- for the stage tests
 
+// the stages one by one (pixels.hip, bottom): a = in/out array, b = table or precision, c = out array, n = elements / blocks /
+// pixels, p0.. = P (transforms) or components, X, Y, size_x (colour; P travels in b)
+enum { JH_STAGE_DEQUANTIZE, JH_STAGE_QUANTIZE, JH_STAGE_IDCT, JH_STAGE_FDCT, JH_STAGE_TO_RGB, JH_STAGE_TO_YCC };
+int jh_launch_stage(int what, void *a, const void *b, void *c, size_t n, int p0, int p1, int p2, size_t p3, hipStream_t s);
+
 int jh_launch_selftest_divide(unsigned long long *d_out, int per, unsigned seed, hipStream_t stream);
 int jh_launch_selftest_ycc8(unsigned long long *d_out, hipStream_t stream);
 

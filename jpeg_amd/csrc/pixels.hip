@@ -1222,3 +1222,137 @@ int jh_launch_selftest_divide(unsigned long long *d_out, int per, unsigned seed,
 	hipLaunchKernelGGL(k_selftest_divide, dim3(256), dim3(256), 0, stream, d_out, per, seed);
 	return hipGetLastError() == hipSuccess ? 0 : -1;
 }
+
+// ================================================================================== the stages one by one
+//
+// dequantize / inverse_dct / forward_dct / quantize (imgproc.h:8-16) and frame_to_rgb / frame_to_ycc (frame.h:21,33) as
+// kernels of their own, on the reference's own buffer layouts (flt_block / int_block arrays, the interleaved float
+// frame): what integration/ref_glue.c (-DGLUE_STAGES) puts behind the reference's function names, so that every FLOAT
+// stage boundary of the reference exists on the GPU as well.  Parity vehicles: the fused kernels above are the fast
+// path.  Same arithmetic as there: dct1<>, the literal table, no contraction, binary64 where C promotes.
+
+// dequantize_block (imgproc.c:10-19): f[j] = (float)(c[j] * (int32)Q[j]), Q in raster order
+__global__ __launch_bounds__(256) void k_stage_dequantize(const int32_t *coef, const uint16_t *Q, float *out, size_t n)
+{
+	const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (i < n) {
+		out[i] = (float)(int32_t)((uint32_t)coef[i] * (uint32_t)Q[i & 63]);      // (wraps like the int32 product does)
+	}
+}
+
+// quantize_block (imgproc.c:21-30): c[j] = (int32)roundf(f[j] / (float)Q[j]) -- the compiler's correctly rounded
+// division and round_half_away() (== roundf for every float, tests/test_round_cpu.py)
+__global__ __launch_bounds__(256) void k_stage_quantize(const float *in, const uint16_t *Q, int32_t *out, size_t n)
+{
+	const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (i < n) {
+		out[i] = round_half_away(in[i] / (float)Q[i & 63]);
+	}
+}
+
+// inverse_dct (imgproc.c:172-200): idct (rows, then columns, :130-149), then c[j] += shift;
+// forward_dct (imgproc.c:202-230): c[j] -= shift, then fdct (rows, then columns, :151-170).  One thread per block.
+template <bool INV>
+__global__ __launch_bounds__(64) void k_stage_dct(float *blocks, size_t nblocks, float shiftf)
+{
+	const size_t b = (size_t)blockIdx.x * 64 + threadIdx.x;
+	if (b >= nblocks) {
+		return;
+	}
+	float *p = blocks + b * 64;
+	float c[8][8];
+#pragma unroll
+	for (int v = 0; v < 8; ++v) {
+#pragma unroll
+		for (int u = 0; u < 8; ++u) {
+			c[v][u] = INV ? p[v * 8 + u] : p[v * 8 + u] - shiftf;
+		}
+	}
+#pragma unroll
+	for (int v = 0; v < 8; ++v) {                             // rows
+		float o[8];
+		dct1<INV>(c[v], o);
+#pragma unroll
+		for (int u = 0; u < 8; ++u) {
+			c[v][u] = o[u];
+		}
+	}
+#pragma unroll
+	for (int u = 0; u < 8; ++u) {                             // columns
+		float in[8], o[8];
+#pragma unroll
+		for (int v = 0; v < 8; ++v) {
+			in[v] = c[v][u];
+		}
+		dct1<INV>(in, o);
+#pragma unroll
+		for (int v = 0; v < 8; ++v) {
+			p[v * 8 + u] = INV ? o[v] + shiftf : o[v];
+		}
+	}
+}
+
+// frame_to_rgb (frame.c:188-244) / frame_to_ycc (frame.c:154-186) on the interleaved float frame, x < X and y < Y only
+template <bool TO_RGB>
+__global__ __launch_bounds__(256) void k_stage_colour(float *data, int comps, int X, int Y, size_t size_x, int P)
+{
+	const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (i >= (size_t)X * Y) {
+		return;
+	}
+	const size_t y = i / (size_t)X, x = i - y * (size_t)X;
+	float *px = data + (y * size_x + x) * comps;
+	const int shift = 1 << (P - 1), denom = 1 << P;
+	if (TO_RGB) {
+		const float Yl = px[0], Cb = px[1], Cr = px[2];
+		const float r_ = Yl + 1.402 * (Cr - shift);
+		const float g_ = Yl - 0.34414 * (Cb - shift) - 0.71414 * (Cr - shift);
+		const float b_ = Yl + 1.772 * (Cb - shift);
+		if (comps == 4) {
+			const float K = px[3];
+			px[0] = K - (r_ * K) / denom;
+			px[1] = K - (g_ * K) / denom;
+			px[2] = K - (b_ * K) / denom;
+			px[3] = 255.0f;
+		} else {
+			px[0] = r_;
+			px[1] = g_;
+			px[2] = b_;
+		}
+	} else {
+		const float R = px[0], G_ = px[1], B_ = px[2];
+		const float Yl = 0.299 * R + 0.587 * G_ + 0.114 * B_;
+		const float Cb = - 0.1687 * R - 0.3313 * G_ + 0.5 * B_ + shift;
+		const float Cr = 0.5 * R - 0.4187 * G_ - 0.0813 * B_ + shift;
+		px[0] = Yl;
+		px[1] = Cb;
+		px[2] = Cr;
+	}
+}
+
+int jh_launch_stage(int what, void *a, const void *b, void *c, size_t n, int p0, int p1, int p2, size_t p3, hipStream_t s)
+{
+	switch (what) {
+	case JH_STAGE_DEQUANTIZE:
+		hipLaunchKernelGGL(k_stage_dequantize, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const int32_t *)a, (const uint16_t *)b, (float *)c, n);
+		break;
+	case JH_STAGE_QUANTIZE:
+		hipLaunchKernelGGL(k_stage_quantize, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float *)a, (const uint16_t *)b, (int32_t *)c, n);
+		break;
+	case JH_STAGE_IDCT:
+		hipLaunchKernelGGL(k_stage_dct<true>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, (float *)a, n, (float)(1 << (p0 - 1)));
+		break;
+	case JH_STAGE_FDCT:
+		hipLaunchKernelGGL(k_stage_dct<false>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, (float *)a, n, (float)(1 << (p0 - 1)));
+		break;
+	case JH_STAGE_TO_RGB:
+		hipLaunchKernelGGL(k_stage_colour<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (float *)a, p0, p1, p2, p3, (int)(size_t)b);
+		break;
+	case JH_STAGE_TO_YCC:
+		hipLaunchKernelGGL(k_stage_colour<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (float *)a, p0, p1, p2, p3, (int)(size_t)b);
+		break;
+	default:
+		return -1;
+	}
+	return hipGetLastError() == hipSuccess ? 0 : -1;
+}

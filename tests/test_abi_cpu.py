@@ -64,7 +64,7 @@ def test_ref_glue_compiles_against_the_reference_headers(built_lib, tmp_path):
     import subprocess
     if shutil.which("gcc") is None or not os.path.isdir("/root/reference"):
         pytest.skip("needs gcc and /root/reference")
-    for which in ("GLUE_DECODER", "GLUE_ENCODER"):
+    for which in ("GLUE_DECODER", "GLUE_ENCODER", "GLUE_STAGES"):
         subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-D_XOPEN_SOURCE=700",
                         "-I/root/reference", "-I" + os.path.join(ROOT, "include"), "-D" + which, "-c",
                         os.path.join(ROOT, "integration", "ref_glue.c"), "-o", str(tmp_path / (which + ".o"))],

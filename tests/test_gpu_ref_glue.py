@@ -22,7 +22,7 @@ from tests.conftest import golden_path
 pytestmark = pytest.mark.gpu
 
 REF = os.path.join(ORACLE_DIR, "_ref")
-PROGS = {n: os.path.join(REF, n) for n in ("decoder", "encoder", "decoder_hip", "encoder_hip")}
+PROGS = {n: os.path.join(REF, n) for n in ("decoder", "encoder", "decoder_hip", "encoder_hip", "decoder_stages", "encoder_stages")}
 
 
 @pytest.fixture(scope="module")
@@ -74,6 +74,17 @@ def test_encoder_and_decoder_programs(progs, tmp_path, name, case):
     assert d0.returncode == 0 and d1.returncode == 0, d1.stdout[-2000:]
     assert read(tmp_path / "hip.pnm") == read(tmp_path / "ref.pnm")
 
+    # Stage by stage (SURVEY.md section 8b's table): ALL of the reference's drivers and loops, its Huffman coder included,
+    # with dequantize / inverse_dct / frame_to_rgb and frame_to_ycc / forward_dct / quantize from the library under the
+    # reference's own names (integration/ref_glue.c -DGLUE_STAGES): one GPU kernel per stage, the float buffers between
+    # them the reference's own.
+    r2 = run([progs["encoder_stages"]] + args + ["stages.jpg"], tmp_path)
+    assert r2.returncode == 0 and b"Failure" not in r2.stdout, r2.stdout[-2000:]
+    assert read(tmp_path / "stages.jpg") == jpg
+    d2 = run([progs["decoder_stages"], "ref.jpg", "stages.pnm"], tmp_path)
+    assert d2.returncode == 0, d2.stdout[-2000:]
+    assert read(tmp_path / "stages.pnm") == read(tmp_path / "ref.pnm")
+
 
 @pytest.mark.parametrize("name,case", DEC, ids=[n for n, _ in DEC])
 def test_decoder_program_on_foreign_streams(progs, tmp_path, name, case):
@@ -90,3 +101,10 @@ def test_decoder_program_on_foreign_streams(progs, tmp_path, name, case):
         assert read(tmp_path / "a" / o) == read(tmp_path / "b" / o), o
     if case["err"] == 0:
         assert outs0 in (["output.ppm"], ["output.pgm"])
+    # and stage by stage (CMYK: the four-component frame_to_rgb, frame.c:196-217)
+    (tmp_path / "c").mkdir()
+    d2 = run([progs["decoder_stages"], src], tmp_path / "c")
+    assert d2.returncode == d0.returncode, d2.stdout[-2000:]
+    assert sorted(os.listdir(tmp_path / "c")) == outs0
+    for o in outs0:
+        assert read(tmp_path / "a" / o) == read(tmp_path / "c" / o), o

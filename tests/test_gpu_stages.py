@@ -275,3 +275,35 @@ def test_float_frame_of_a_four_component_file(hip, oracle):
     want = np.ascontiguousarray(dinfo.frame[:dinfo.Y, :dinfo.X, :3])
     assert np.array_equal(tap[0].cpu().numpy().view(np.uint32), want.view(np.uint32))
     d.close()
+
+
+def test_single_stage_entry_points_against_the_oracles_primitives(hip, oracle):
+    """jpeg_hip_dequantize_blocks / quantize_blocks / inverse_dct_blocks / forward_dct_blocks (imgproc.h:8-16 on the
+    reference's flt_block / int_block arrays): every block bit for bit against the oracle's block primitives, which
+    tests/test_oracle_vs_ref.py pins to the compiled reference's dequantize_block / quantize_block / idct / fdct."""
+    L = hip.lib()
+    rng = np.random.default_rng(5)
+    n = 300
+    Q = oracle.qtable(0, 37).astype(np.uint16)
+    coef = rng.integers(-1200, 1200, (n, 64)).astype(np.int32)
+    coef[rng.random((n, 64)) < 0.6] = 0
+    f = np.zeros((n, 64), np.float32)
+    assert L.jpeg_hip_dequantize_blocks(0, n, coef.ctypes.data, Q.ctypes.data, f.ctypes.data) == 0
+    want = np.stack([oracle.dequantize(coef[b], Q) for b in range(n)])
+    assert np.array_equal(f.view(np.uint32), want.view(np.uint32))
+    for P in (8, 12):
+        g = f.copy()
+        assert L.jpeg_hip_inverse_dct_blocks(0, n, g.ctypes.data, P) == 0
+        want = np.stack([oracle.idct(f[b]) + np.float32(1 << (P - 1)) for b in range(n)]).astype(np.float32)
+        assert np.array_equal(g.view(np.uint32), want.view(np.uint32)), P
+        h = g.copy()
+        assert L.jpeg_hip_forward_dct_blocks(0, n, h.ctypes.data, P) == 0
+        want = np.stack([oracle.fdct((g[b] - np.float32(1 << (P - 1))).astype(np.float32)) for b in range(n)])
+        assert np.array_equal(h.view(np.uint32), want.view(np.uint32)), P
+        q = np.zeros((n, 64), np.int32)
+        assert L.jpeg_hip_quantize_blocks(0, n, h.ctypes.data, Q.ctypes.data, q.ctypes.data) == 0
+        want = np.stack([oracle.quantize(h[b], Q) for b in range(n)])
+        assert np.array_equal(q, want), P
+    zero = Q.copy()
+    zero[9] = 0
+    assert L.jpeg_hip_quantize_blocks(0, n, f.ctypes.data, zero.ctypes.data, coef.ctypes.data) == hip.RET_FAILURE_FILE_UNSUPPORTED
