@@ -1015,12 +1015,14 @@ __global__ __launch_bounds__(256) void k_encode_pixels(const EncPixArgs a)
 
 	// ---- 5: (block, half): what write_ac() will spend on the block (coeffs.c:164-194, Figure F.2), walked over
 	// the nonzero coefficients only (the zero run is the distance to the previous one).  Two lanes per block,
-	// coefficients 1..31 and 32..63, the halves in different waves (the first half holds most of the work);
+	// coefficients 1..31 and 32..63, the halves in different lanes (the first half holds most of the work);
 	// the next coefficient is fetched while the current symbol is priced.
 	static_assert(TILE_BLOCKS <= 128, "stage 5 maps a tile's blocks to 128 lanes");
 	const int nb = ntask >> 3;
 	{
-		const int h = tid >> 7, b = tid & 127;
+		// first halves on threads 0 .. nb - 1, second halves (few nonzeros) behind them: three waves instead of two
+		// pairs of a full and a half-empty one, and the fourth is done
+		const int h = tid >= nb ? 1 : 0, b = h ? tid - nb : tid;
 		if (b < nb) {
 			const int mcu = B == 1 ? b : (int)(__umul24((unsigned)b, L.b_magic16) >> 16);
 			const int k = b - (int)__umul24((unsigned)mcu, (unsigned)B);
