@@ -172,7 +172,7 @@ def pmc_valu(kernel, frames, kernel_ms, clock_ghz=2.4, simds=1024):
             "busy_frac": round(busy, 4), "clock_ghz": clock_ghz, "source": profile_source(d, fname)}
 
 
-def measure_workload(torch, binding, synth, name, nframes, device, steps, restart_interval=0):
+def measure_workload(torch, binding, synth, name, nframes, device, steps, restart_interval=0, lanes=1):
     """decode and encode rates of one BASELINE configuration on one GPU, device-resident, with the per-kernel
     HIP-event times and the algorithmic-byte roofline of its dominant kernel."""
     enc, samples, jpgs, cfg = make_batch(torch, binding, synth, name, nframes, device, restart_interval)
@@ -180,9 +180,15 @@ def measure_workload(torch, binding, synth, name, nframes, device, steps, restar
     dec.prepare(jpgs)
     out = dec.alloc_output()
     pix = cfg["X"] * cfg["Y"]
-    t_d = timed(torch, lambda: dec.run(out), steps, 2, None)
+    t_d1 = timed(torch, lambda: dec.run(out), steps, 2, None)
+    assert all(s == 0 for s in dec.sync())
+    sums1 = frame_sums(torch, out)
+    lanes_got = dec.set_lanes(lanes) if lanes > 1 else 1
+    out.zero_()
+    t_d = timed(torch, lambda: dec.run(out), steps, 2, None) if lanes > 1 else t_d1
     t_e = timed(torch, lambda: enc.run(samples), steps, 2, None)
     assert all(s == 0 for s in dec.sync()) and all(s == 0 for s in enc.sync()[0])
+    assert torch.equal(frame_sums(torch, out), sums1), "the lanes decoded something else than one stream"
     stats = dec.stats(0)
     allk = kernel_times(dec, lambda: dec.run(out), torch, reps=3)
     allk.update(kernel_times(enc, lambda: enc.run(samples), torch, reps=3))
@@ -192,6 +198,7 @@ def measure_workload(torch, binding, synth, name, nframes, device, steps, restar
     res = {
         "frames_per_step": nframes, "distinct_frames": nframes,
         "decode_mpix_s": round(nframes * pix * steps / t_d / 1e6, 1),
+        "decode_mpix_s_one_lane": round(nframes * pix * steps / t_d1 / 1e6, 1), "decoder_lanes": lanes_got,
         "encode_mpix_s": round(nframes * pix * steps / t_e / 1e6, 1),
         "jpeg_bytes_per_frame": sum(len(j) for j in jpgs) // nframes,
         "alg_bytes_per_step": alg,
@@ -475,6 +482,9 @@ def main():
                          "counter collection of ROCm 7.2 crashes inside torch's int64 kernels of the device-side generator)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; gloo rehearses the multi-rank path "
                                                       "with several ranks on ONE GPU (RCCL refuses that)")
+    ap.add_argument("--lanes", type=int, default=3,
+                    help="streams the decoder lays a batch out over (jpeg_hip_decoder_set_lanes); with the encoder's "
+                         "stream beside them, 3 fills the four hardware queues of a process")
     ap.add_argument("--one-stream", action="store_true",
                     help="decode and encode on ONE stream (for rocprofv3 --stats: kernels of the two pipelines then "
                          "do not overlap and their durations are the ones `kernel_ms` reports)")
@@ -519,8 +529,21 @@ def main():
 
     # the decode batch and the encode batch of a step are independent jobs: each runs on a stream of its
     # own, so the short, narrow kernels of one pipeline (scans, walk rounds) overlap the wide ones of the other
-    s_dec = torch.cuda.Stream(dev)
-    s_enc = s_dec if args.one_stream else torch.cuda.Stream(dev)
+    # (streams picked by measurement, a hardware queue each: the decoder's own stream, the encoder's, and the
+    # decoder's other lanes -- jpeg_hip_decoder_set_lanes: narrow kernels of one run of frames beside the wide ones
+    # of the others)
+    lanes = 1 if args.one_stream else max(1, min(args.lanes, 4))
+    if args.one_stream:
+        s_dec = s_enc = torch.cuda.Stream(dev)
+        queues = None
+    else:
+        queues = binding.StreamSet(dev, min(4, lanes + 1), avoid_current=False)
+        s_dec, s_enc = queues.streams[0], queues.streams[1]
+        lane_streams = queues.streams[2:2 + lanes - 1]
+        while len(lane_streams) < lanes - 1:             # more lanes than queues: the last ones share the encoder's
+            lane_streams.append(s_enc)
+        with torch.cuda.stream(s_dec):
+            dec.set_lanes(lanes, lane_streams)
 
     def step():
         with torch.cuda.stream(s_dec):
@@ -540,8 +563,23 @@ def main():
     assert all(s == 0 for s in dec.sync()) and all(s == 0 for s in enc.sync()[0])
     value = world * F * pix * args.steps / t / 1e6
 
-    t_d = timed(torch, lambda: dec.run(out), args.steps, 1, dist)
-    t_e = timed(torch, lambda: enc.run(samples), args.steps, 1, dist)
+    def dec_alone():
+        with torch.cuda.stream(s_dec):
+            dec.run(out)
+
+    def enc_alone():
+        with torch.cuda.stream(s_enc):
+            enc.run(samples)
+
+    t_d = timed(torch, dec_alone, args.steps, 1, dist)
+    t_e = timed(torch, enc_alone, args.steps, 1, dist)
+    t_d1 = t_d
+    if lanes > 1:
+        sums = frame_sums(torch, out)
+        dec.set_lanes(1)
+        out.zero_()
+        t_d1 = timed(torch, dec_alone, args.steps, 1, dist)
+        assert torch.equal(frame_sums(torch, out), sums), "the lanes decoded something else than one stream"
 
     res = {
         "metric": "Mpix/s decode+encode, 4K 4:2:0 q90 (every pixel is decoded AND encoded once per step)",
@@ -554,6 +592,7 @@ def main():
                    "frames_per_gpu_per_step": F, "distinct_frames": min(F, HOST_SYNTH) if HOST_SYNTH else F,
                    "parallelism": "frames sharded over %d GPU(s), no collectives" % world},
         "decode_mpix_s": round(world * F * pix * args.steps / t_d / 1e6, 1),
+        "decode_mpix_s_one_lane": round(world * F * pix * args.steps / t_d1 / 1e6, 1), "decoder_lanes": lanes,
         "encode_mpix_s": round(world * F * pix * args.steps / t_e / 1e6, 1),
     }
 
@@ -562,6 +601,8 @@ def main():
         # slowest chains decide it): a second decoder on twice the frames shows what they cost at this batch size.
         dec2 = binding.Decoder(dev)
         dec2.prepare(jpgs + jpgs)
+        if lanes > 1:
+            dec2.set_lanes(lanes)
         out2 = dec2.alloc_output()
         dec2.run(out2)
         assert all(s == 0 for s in dec2.sync())
@@ -592,6 +633,8 @@ def main():
     cpu_jpgs = jpgs[:4]
     enc.close()
     dec.close()
+    if queues is not None:
+        queues.close()
     del out, samples
 
     if rank == 0 and world == 1 and not args.no_workloads:
@@ -599,40 +642,12 @@ def main():
         res["workloads"] = {}
         for name, nf, ri in (("c2_4k_444_q90", 32, 480), ("c3_8k_gray12_q95", 16, 0), ("c4_8k_420_q95", 16, 0),
                              ("c5_1080p_422_q85", args.mjpeg_frames, 0)):
-            w = measure_workload(torch, binding, synth, name, nf, dev, args.steps, ri)
+            # (no encoder beside the decoder in these lines: a fourth lane takes the queue the encoder has in `value`)
+            w = measure_workload(torch, binding, synth, name, nf, dev, args.steps, ri, lanes + 1 if lanes > 1 else 1)
             if name.startswith("c5"):
                 w["decode_frames_per_s"] = round(w["decode_mpix_s"] * 1e6 / (1920 * 1080), 1)
                 w["encode_frames_per_s"] = round(w["encode_mpix_s"] * 1e6 / (1920 * 1080), 1)
             res["workloads"][name + ("_ri%d" % ri if ri else "")] = w
-
-    if rank == 0 and world == 1 and not args.no_workloads:
-        # What a decode-only job gets that lays the metric's F frames out over three decoder objects with a stream
-        # each (the narrow kernels of one part beside the wide ones of the others; a process has four hardware
-        # queues, so three such streams and no encoder beside them is as far as this goes).  Measured BEFORE the
-        # Motion JPEG pipelines on purpose: those must not depend on which streams the process used earlier (round 2:
-        # 46 k instead of 72 k frames/s in this order; their streams are now picked by measurement, binding.StreamSet).
-        third = (F + 2) // 3
-        parts = [jpgs[k:k + third] for k in range(0, F, third)]
-        decs3, outs3 = [], []
-        for js in parts:
-            dd = binding.Decoder(dev)
-            dd.prepare(js)
-            decs3.append(dd)
-            outs3.append(dd.alloc_output())
-        streams3 = [torch.cuda.Stream(dev) for _ in parts]
-
-        def decode3():
-            for dd, oo, ss in zip(decs3, outs3, streams3):
-                with torch.cuda.stream(ss):
-                    dd.run(oo)
-
-        decode3()
-        assert all(s == 0 for dd in decs3 for s in dd.sync())
-        t3 = timed(torch, decode3, args.steps, 1, None)
-        res["decode_mpix_s_three_decoders"] = round(F * pix * args.steps / t3 / 1e6, 1)
-        for dd in decs3:
-            dd.close()
-        del outs3
 
     if not args.no_mjpeg:
         ms = mjpeg_stream(torch, binding, synth, mjpeg, dev, rank, world, dist, args.mjpeg_frames)

@@ -175,6 +175,21 @@ void jpeg_hip_decoder_set_tolerant(jpeg_hip_decoder *dec, int on);
  * this decoder's work) and returns with the DMA of the codestreams in flight.  The stream must outlive the
  * decoder's use of it.  No counterpart in the reference. */
 void jpeg_hip_decoder_set_upload_stream(jpeg_hip_decoder *dec, void *stream, int on);
+/* Lanes.  n = 1 ... 4 (1: as before).  run() lays the batch's frames out over n streams -- run()'s own and n - 1
+ * of the decoder's, measured like jpeg_hip_streams_create() does to run beside `stream` (the stream run() will be
+ * given) and beside each other -- so that the narrow kernels of one run of frames (scans, chain links, survivors:
+ * a few waves per SIMD that wait on each other) execute beside the wide ones of the others.  Nothing else changes:
+ * the lanes start behind what run()'s stream holds at the call, that stream waits for them, results and sync() are
+ * the same.  4K 4:2:0 q90, 128 frames: 180 -> 204 Gpix/s with 3 lanes; 8K 12-bit gray q95: 92 -> 118 (DESIGN.md
+ * section 5).  A process has four hardware queues: lanes beyond what is free share a queue and gain nothing, so
+ * pipelines that already keep several decoders busy (jpeg_amd/mjpeg.py) stay at 1.  Returns the number of lanes
+ * seen to run side by side (<= n), negative on error.  Call between batches (it waits for a run() in flight).
+ * lane_streams: NULL, or n - 1 streams of the caller's to use instead of the decoder's own (a caller that lays
+ * out the four queues itself with jpeg_hip_streams_create(): one for its encoder, the rest for this; they must
+ * outlive their use here, and the return value is then n, unmeasured).  The environment variable JPEG_AMD_LANES
+ * (1 ... 4) sets the lanes of decoders that were never told, at their first run().
+ * No counterpart in the reference (decoder.c:603-612 decodes one frame at a time on one thread). */
+int  jpeg_hip_decoder_set_lanes(jpeg_hip_decoder *dec, int n, void *stream, void *const *lane_streams);
 /* compressed bytes actually consumed per frame (entropy-coded segment incl. RSTn), for roofline accounting */
 int  jpeg_hip_decoder_ecs_bytes(const jpeg_hip_decoder *dec, size_t *ecs_len);
 

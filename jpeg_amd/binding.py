@@ -32,7 +32,7 @@ EXPORTS = [
     "jpeg_hip_decoder_info", "jpeg_hip_decoder_frame_bytes", "jpeg_hip_decoder_run",
     "jpeg_hip_decoder_sync", "jpeg_hip_decoder_get_coefficients", "jpeg_hip_decoder_set_timing",
     "jpeg_hip_decoder_get_timing", "jpeg_hip_decoder_ecs_bytes", "jpeg_hip_decoder_get_stats",
-    "jpeg_hip_decoder_set_debug", "jpeg_hip_decoder_get_chain_steps", "jpeg_hip_decoder_set_tolerant", "jpeg_hip_decoder_set_upload_stream", "jpeg_hip_mjpeg_split",
+    "jpeg_hip_decoder_set_debug", "jpeg_hip_decoder_get_chain_steps", "jpeg_hip_decoder_set_tolerant", "jpeg_hip_decoder_set_upload_stream", "jpeg_hip_decoder_set_lanes", "jpeg_hip_mjpeg_split",
     "jpeg_hip_encoder_create", "jpeg_hip_encoder_destroy", "jpeg_hip_encoder_configure",
     "jpeg_hip_encoder_info", "jpeg_hip_encoder_run", "jpeg_hip_encoder_sync",
     "jpeg_hip_encoder_run_stream", "jpeg_hip_encoder_sync_stream",
@@ -138,6 +138,7 @@ def lib():
         L.jpeg_hip_decoder_set_debug.restype = None
         L.jpeg_hip_decoder_set_upload_stream.argtypes = [vp, vp, C.c_int]
         L.jpeg_hip_decoder_set_upload_stream.restype = None
+        L.jpeg_hip_decoder_set_lanes.argtypes = [vp, C.c_int, vp, C.POINTER(vp)]
         L.jpeg_hip_decoder_set_tolerant.argtypes = [vp, C.c_int]
         L.jpeg_hip_decoder_set_tolerant.restype = None
         L.jpeg_hip_mjpeg_split.argtypes = [C.c_char_p, sz, C.POINTER(sz), C.POINTER(sz), C.c_int]
@@ -409,6 +410,20 @@ class Decoder:
         else:
             self.L.jpeg_hip_decoder_set_upload_stream(self.h, C.c_void_p(stream.cuda_stream), 1)
         self._upload_stream = stream                     # keeps it alive
+
+    def set_lanes(self, n, streams=None):
+        """run() splits the batch over n streams (its own, the current torch stream, and n - 1 of the decoder's that
+        are measured to run beside it, or the n - 1 torch streams given): narrow kernels of one part beside the wide
+        ones of the others.  Returns how many lanes really run side by side."""
+        arr = None
+        if streams is not None:
+            assert len(streams) == n - 1
+            arr = (C.c_void_p * max(1, n - 1))(*[C.c_void_p(s.cuda_stream) for s in streams])
+        self._lane_streams = streams                     # kept alive
+        got = self.L.jpeg_hip_decoder_set_lanes(self.h, int(n), _stream_ptr(self.device), arr)
+        if got < 0:
+            raise JpegError(RET_FAILURE_LOGIC_ERROR, "jpeg_hip_decoder_set_lanes")
+        return got
 
     def set_tolerant(self, on=True):
         """Skip APP9/APP10/APP15/DNL/JPGn segments instead of failing like the reference (call before prepare)."""

@@ -11,6 +11,7 @@
 #include <string.h>
 #include <ctype.h>
 #include <vector>
+#include <algorithm>
 #include <map>
 #include <thread>
 #include <utility>
@@ -258,6 +259,7 @@ static int fill_threads()
 	return n;
 }
 
+#define JH_MAX_LANES 4                 // one per hardware queue of the process
 #define JH_UPLOAD_PIECE (8u << 20)     // bytes per DMA of a batch that is uploaded from caller-pinned memory
 
 struct jpeg_hip_decoder {
@@ -289,6 +291,14 @@ struct jpeg_hip_decoder {
 	bool up_user = false;
 	hipEvent_t uploaded = nullptr;        // ... and run() makes its stream wait for this
 	hipEvent_t done = nullptr;            // end of run()'s kernels: sync() waits for it, not for the whole stream
+	// jpeg_hip_decoder_set_lanes(): run() lays the batch's frames out over `lanes` streams -- the caller's and these --
+	// so that the narrow kernels of one part (scans, links, survivors: a few waves per SIMD, waiting on each other)
+	// run beside the wide ones of the others
+	int lanes = 1;
+	bool lanes_chosen = false;            // by a call; otherwise JPEG_AMD_LANES (1 ... 4) applies at the first run()
+	bool lanes_owned = false;             // the lane streams are this object's (not handed in by the caller)
+	hipStream_t lane_stream[JH_MAX_LANES - 1] = {nullptr, nullptr, nullptr};
+	hipEvent_t lane_fork = nullptr, lane_done[JH_MAX_LANES - 1] = {nullptr, nullptr, nullptr};
 	bool ran = false;
 	int debug = 0;
 	bool tolerant = false;
@@ -350,6 +360,28 @@ extern "C" int jpeg_hip_decoder_create(jpeg_hip_decoder **dec, int device)
 	return RET_SUCCESS;
 }
 
+static void decoder_drop_lanes(jpeg_hip_decoder *dec)
+{
+	for (int k = 0; k < JH_MAX_LANES - 1; ++k) {
+		if (dec->lane_stream[k]) {
+			hipStreamSynchronize(dec->lane_stream[k]);
+			if (dec->lanes_owned) {
+				hipStreamDestroy(dec->lane_stream[k]);
+			}
+			dec->lane_stream[k] = nullptr;
+		}
+		if (dec->lane_done[k]) {
+			hipEventDestroy(dec->lane_done[k]);
+			dec->lane_done[k] = nullptr;
+		}
+	}
+	if (dec->lane_fork) {
+		hipEventDestroy(dec->lane_fork);
+		dec->lane_fork = nullptr;
+	}
+	dec->lanes = 1;
+}
+
 extern "C" void jpeg_hip_decoder_destroy(jpeg_hip_decoder *dec)
 {
 	if (dec) {
@@ -370,6 +402,7 @@ extern "C" void jpeg_hip_decoder_destroy(jpeg_hip_decoder *dec)
 		if (dec->copy_stream) {
 			hipStreamDestroy(dec->copy_stream);
 		}
+		decoder_drop_lanes(dec);
 		delete dec;
 	}
 }
@@ -1181,38 +1214,147 @@ __global__ void k_dec_init(JhDecState *st, int n)
 	}
 }
 
-static int decoder_launch(jpeg_hip_decoder *dec, hipStream_t s)
+// frames [f0, f1) of the batch on stream s: every pass, then -- behind `before_pixels`, if given -- the pixel
+// kernel, and the states' way back
+static int decoder_launch_range(jpeg_hip_decoder *dec, int f0, int f1, hipStream_t s, const JhTimerHook *th, hipEvent_t before_pixels)
 {
-	const JhTimerHook th = dec->timer.hook();
+	const int n = f1 - f0;
 	if (dec->pass.size() != 1 || dec->pass[0].comp != -1) {
 		// scans of single components: blocks no scan reaches stay zero (common.c:129)
-		if (hipMemsetAsync(dec->d_coefs, 0, (size_t)dec->nframes * dec->g.nblk * 64 * sizeof(int16_t), s) != hipSuccess) {
+		if (hipMemsetAsync(dec->d_coefs + (size_t)f0 * dec->g.nblk * 64, 0, (size_t)n * dec->g.nblk * 64 * sizeof(int16_t), s) != hipSuccess) {
 			return RET_FAILURE_LOGIC_ERROR;
 		}
 	}
 	for (DecPass &ps : dec->pass) {
-		hipLaunchKernelGGL(k_dec_init, dim3((dec->nframes + 63) / 64), dim3(64), 0, s, ps.d_state, dec->nframes);
-		if (jh_launch_ecs_unstuff(ps.work, s, &th)) {
+		JhDecodeWork w = ps.work;                          // the kernels index frames[], state[] and coefs by frame
+		w.frames += f0;
+		w.state += f0;
+		w.coefs += (size_t)f0 * (w.rm.mode ? w.rm.nblk_full : ps.g.nblk) * 64;
+		w.nframes = n;
+		hipLaunchKernelGGL(k_dec_init, dim3((n + 63) / 64), dim3(64), 0, s, ps.d_state + f0, n);
+		if (jh_launch_ecs_unstuff(w, s, th)) {
 			return RET_FAILURE_LOGIC_ERROR;
 		}
-		if (jh_launch_huff_decode(ps.work, ps.g, s, &th)) {
+		if (jh_launch_huff_decode(w, ps.g, s, th)) {
 			return RET_FAILURE_LOGIC_ERROR;
 		}
 	}
+	if (before_pixels && hipStreamWaitEvent(s, before_pixels, 0) != hipSuccess) {
+		return RET_FAILURE_LOGIC_ERROR;
+	}
 	if (!dec->coefs_only) {                                // jpeg_hip_read_scan: the coefficients are the result
 		dec->timer.begin("k_decode_pixels", s);
-		if (jh_launch_decode_pixels(dec->g, dec->nframes, dec->d_coefs, dec->d_quant, dec->last_out, dec->last_stride, s, dec->float_tap)) {
+		if (jh_launch_decode_pixels(dec->g, n, dec->d_coefs + (size_t)f0 * dec->g.nblk * 64, dec->d_quant + f0,
+		                            (uint8_t *)dec->last_out + (size_t)f0 * dec->last_stride, dec->last_stride, s, dec->float_tap)) {
 			return RET_FAILURE_LOGIC_ERROR;
 		}
 		dec->timer.end(s);
 	}
 	// the frames' states come back on the same stream, into page-locked memory: sync() needs the event only
 	for (DecPass &ps : dec->pass) {
-		if (hipMemcpyAsync(ps.h_state, ps.d_state, dec->nframes * sizeof(JhDecState), hipMemcpyDeviceToHost, s) != hipSuccess) {
+		if (hipMemcpyAsync(ps.h_state + f0, ps.d_state + f0, n * sizeof(JhDecState), hipMemcpyDeviceToHost, s) != hipSuccess) {
+			return RET_FAILURE_LOGIC_ERROR;
+		}
+	}
+	return RET_SUCCESS;
+}
+
+// run(): the batch on the caller's stream s, or laid out over the lanes.  A lane other than the first is a stream
+// of its own that works on the same frames in every run().  Its entropy kernels touch nothing but those frames'
+// part of the decoder's buffers, so they wait for the codestreams' upload only and may start while s -- and the
+// other lanes -- are still busy with the run() before: back-to-back calls then drift apart the way separate
+// decoder objects would, narrow kernels beside wide ones.  What the caller's stream orders -- the output buffer,
+// whatever was queued on s before this call -- is waited for in front of the pixel kernel, and s waits for the
+// lanes' ends.  (Upload on the caller's stream, set_upload_stream: the order of s is all there is; the lanes wait
+// for it at their start.)
+static int decoder_launch(jpeg_hip_decoder *dec, hipStream_t s)
+{
+	const JhTimerHook th = dec->timer.hook();
+	// lanes: not while kernels are timed one by one or a stage test taps the float frame (both count on one stream)
+	const int lanes = dec->timer.on || dec->float_tap ? 1 : std::min(dec->lanes, dec->nframes);
+	if (lanes > 1 && hipEventRecord(dec->lane_fork, s) != hipSuccess) {
+		return RET_FAILURE_LOGIC_ERROR;
+	}
+	for (int k = 0; k < lanes; ++k) {
+		const int f0 = (int)((long long)dec->nframes * k / lanes), f1 = (int)((long long)dec->nframes * (k + 1) / lanes);
+		const hipStream_t ls = k == 0 ? s : dec->lane_stream[k - 1];
+		hipEvent_t before_pixels = nullptr;
+		if (k > 0) {
+			if (dec->up_user) {
+				if (hipStreamWaitEvent(ls, dec->lane_fork, 0) != hipSuccess) {
+					return RET_FAILURE_LOGIC_ERROR;
+				}
+			} else {
+				if (hipStreamWaitEvent(ls, dec->uploaded, 0) != hipSuccess) {
+					return RET_FAILURE_LOGIC_ERROR;
+				}
+				before_pixels = dec->lane_fork;
+			}
+		}
+		const int err = decoder_launch_range(dec, f0, f1, ls, &th, before_pixels);
+		if (err) {
+			return err;
+		}
+		if (k > 0 && hipEventRecord(dec->lane_done[k - 1], ls) != hipSuccess) {
+			return RET_FAILURE_LOGIC_ERROR;
+		}
+	}
+	for (int k = 1; k < lanes; ++k) {
+		if (hipStreamWaitEvent(s, dec->lane_done[k - 1], 0) != hipSuccess) {
 			return RET_FAILURE_LOGIC_ERROR;
 		}
 	}
 	return hipEventRecord(dec->done, s) == hipSuccess ? RET_SUCCESS : RET_FAILURE_LOGIC_ERROR;
+}
+
+// Lanes.  n = 1 ... 4: run() splits the batch into n runs of frames, the first on its own stream, the others on
+// streams of this object that are measured to run beside `stream` and beside each other (jpeg_hip_streams_create;
+// `stream` = the stream run() will be called with).  Results, order on the caller's stream and sync() are as
+// before: the lanes start behind what the caller's stream holds when run() is called, and the stream waits for
+// them.  lane_streams: NULL, or n - 1 streams of the caller's to use instead (a pipeline that lays out the
+// process's four hardware queues itself, with jpeg_hip_streams_create: bench.py; they must outlive their use here).
+// Returns the number of lanes that were seen to run side by side (n, or fewer when the process's hardware queues
+// are taken; n unmeasured for streams handed in), negative on error.
+extern "C" int jpeg_hip_decoder_set_lanes(jpeg_hip_decoder *dec, int n, void *stream, void *const *lane_streams)
+{
+	if (!dec || n < 1 || n > JH_MAX_LANES) {
+		return -1;
+	}
+	if (hipSetDevice(dec->device) != hipSuccess) {
+		return -1;
+	}
+	if (dec->last_stream) {
+		hipStreamSynchronize(dec->last_stream);            // a run() in flight may be using the lanes
+	}
+	dec->lanes_chosen = true;
+	decoder_drop_lanes(dec);
+	if (n == 1) {
+		return 1;
+	}
+	void *made[JH_MAX_LANES - 1] = {nullptr, nullptr, nullptr};
+	int proven = n - 1;
+	dec->lanes_owned = lane_streams == nullptr;
+	if (lane_streams) {
+		for (int k = 0; k < n - 1; ++k) {
+			made[k] = lane_streams[k];
+		}
+	} else {
+		proven = jpeg_hip_streams_create(dec->device, n - 1, stream, 1, made);
+		if (proven < 0) {
+			return -1;
+		}
+	}
+	bool ok = hipEventCreateWithFlags(&dec->lane_fork, hipEventDisableTiming) == hipSuccess;
+	for (int k = 0; k < n - 1; ++k) {
+		dec->lane_stream[k] = (hipStream_t)made[k];
+		ok = ok && hipEventCreateWithFlags(&dec->lane_done[k], hipEventDisableTiming) == hipSuccess;
+	}
+	if (!ok) {
+		decoder_drop_lanes(dec);
+		return -1;
+	}
+	dec->lanes = n;
+	return 1 + proven;
 }
 
 extern "C" int jpeg_hip_decoder_run(jpeg_hip_decoder *dec, void *d_samples, size_t frame_stride, void *stream)
@@ -1226,6 +1368,13 @@ extern "C" int jpeg_hip_decoder_run(jpeg_hip_decoder *dec, void *d_samples, size
 	HIPCHK(hipSetDevice(dec->device));
 	dec->last_out = d_samples;
 	dec->last_stride = frame_stride;
+	if (!dec->lanes_chosen) {
+		dec->lanes_chosen = true;
+		const char *e = getenv("JPEG_AMD_LANES");
+		if (e && atoi(e) > 1 && jpeg_hip_decoder_set_lanes(dec, std::min(atoi(e), JH_MAX_LANES), stream, nullptr) < 0) {
+			return RET_FAILURE_LOGIC_ERROR;
+		}
+	}
 	dec->last_stream = (hipStream_t)stream;
 	dec->timer.reset();
 	HIPCHK(hipStreamWaitEvent(dec->last_stream, dec->uploaded, 0));    // the codestreams' DMA (copy stream)
