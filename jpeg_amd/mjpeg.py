@@ -214,6 +214,7 @@ def _stream_decoders(device):
         streams = _pipeline_streams(device)
         for d, st in zip(decs, streams):
             d.set_upload_stream(st)
+            d.set_lanes(1)          # the pipeline keeps the queues busy with its decoders (whatever JPEG_AMD_LANES says)
         _stream_state[device] = (decs, streams)
     return _stream_state[device]
 
