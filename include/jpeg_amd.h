@@ -80,9 +80,9 @@ typedef struct jpeg_hip_frame_info {
 int jpeg_hip_device_count(void);
 const char *jpeg_hip_version(void);
 /* Bumped whenever a structure or a signature of this header changes incompatibly (2: jpeg_hip_params lost
- * restart_interval; 3: additions only).  A binding compares jpeg_hip_abi_version() with the JPEG_HIP_ABI_VERSION it
+ * restart_interval; 3 and 4: additions only -- 4 has jpeg_hip_decoder_set_lanes).  A binding compares jpeg_hip_abi_version() with the JPEG_HIP_ABI_VERSION it
  * was built against and refuses to go on when the library is older or has another layout of jpeg_hip_params. */
-#define JPEG_HIP_ABI_VERSION 3
+#define JPEG_HIP_ABI_VERSION 4
 int jpeg_hip_abi_version(void);
 
 /* Host only, no GPU needed: the headers of one codestream up to its first SOS, as parse_format() reads them

@@ -23,7 +23,7 @@ JPEG_HIP_ERR_DC_RANGE = 0x5001
 JPEG_HIP_ERR_NO_CODE = -1
 
 MAX_COMP = 4
-ABI_VERSION = 3          # JPEG_HIP_ABI_VERSION of include/jpeg_amd.h this file mirrors
+ABI_VERSION = 4          # JPEG_HIP_ABI_VERSION of include/jpeg_amd.h this file mirrors
 
 EXPORTS = [
     "jpeg_hip_device_count", "jpeg_hip_version", "jpeg_hip_abi_version", "jpeg_hip_parse_info",

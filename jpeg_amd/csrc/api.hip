@@ -48,10 +48,10 @@ extern "C" int jpeg_hip_device_count(void)
 	return n;
 }
 
-// ABI 3 (round 3): jpeg_hip_encoder_run_stream / sync_stream, jpeg_hip_streams_create / destroy, the float taps,
+// ABI 4 (round 3): jpeg_hip_decoder_set_lanes added.  ABI 3 (round 3): jpeg_hip_encoder_run_stream / sync_stream, jpeg_hip_streams_create / destroy, the float taps,
 // jpeg_hip_selftest_ycc8 added; nothing removed.  ABI 2 (round 2): jpeg_hip_params lost its restart_interval member
 // (now jpeg_hip_encoder_set_restart_interval) -- a caller built against the older header must be rebuilt.
-extern "C" const char *jpeg_hip_version(void) { return "jpeg_amd 0.3 (gfx950, ABI 3)"; }
+extern "C" const char *jpeg_hip_version(void) { return "jpeg_amd 0.3 (gfx950, ABI 4)"; }
 extern "C" int jpeg_hip_abi_version(void) { return JPEG_HIP_ABI_VERSION; }
 
 // host only (no device needed): frames of a Motion JPEG stream
