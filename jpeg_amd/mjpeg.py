@@ -214,7 +214,8 @@ def _stream_decoders(device):
         streams = _pipeline_streams(device)
         for d, st in zip(decs, streams):
             d.set_upload_stream(st)
-            d.set_lanes(1)          # the pipeline keeps the queues busy with its decoders (whatever JPEG_AMD_LANES says)
+            d.set_lanes(1)          # the pipeline keeps the queues busy with its decoders (whatever JPEG_AMD_LANES says:
+                                    # two lanes per decoder were measured, 76 - 78 k frames/s either way)
         _stream_state[device] = (decs, streams)
     return _stream_state[device]
 
