@@ -536,47 +536,92 @@ __global__ __launch_bounds__(256) void k_enc_bitlen(const EncArgs a)
 	}
 }
 
+// per block k of an MCU: component | tables | where the DC predictor of the block is (encoder.c:443-458)
+#define KT_COMP(t) ((t) & 3u)
+#define KT_TD(t) (((t) >> 2) & 1u)
+#define KT_TA(t) (((t) >> 3) & 1u)
+#define KT_INNER(t) (((t) >> 4) & 1u)     // the predictor is the previous block of the same MCU
+#define KT_LASTK(t) (((t) >> 5) & 31u)    // k == B - 1
+#define KT_BACK(t) ((t) >> 16)            // blocks back to the predictor
+
+__device__ __forceinline__ uint32_t make_ktab(const JhGeom &g, int k)
+{
+	const int comp = g.blk_comp[k];
+	const int firstk = g.comp_first[comp];
+	const int lastk = firstk + g.H[comp] * g.V[comp] - 1;
+	const bool inner = k > firstk;
+	const int back = inner ? 1 : k + g.B - lastk;
+	return (uint32_t)comp | ((uint32_t)(g.Td[comp] & 1) << 2) | ((uint32_t)(g.Ta[comp] & 1) << 3) |
+	       ((uint32_t)inner << 4) | ((uint32_t)(k == g.B - 1) << 5) | ((uint32_t)back << 16);
+}
+
 // Default tables: the AC part of every block's length is in JhBlkInfo already (pixel kernel).  The DC symbol
 // (write_dc, coeffs.c:110-126) needs the previous block of the component (encoder.c:443-458): added here,
-// with the workgroup sums and the error conditions, from 4 bytes per block instead of 128.
-__global__ __launch_bounds__(256) void k_enc_dcbits(const EncArgs a)
+// with the sums per group of 256 blocks and the error conditions, from 4 bytes per block instead of 128.
+// A WAVE per group, four blocks per lane: no barrier behind the first, a quarter of the workgroups (the kernel
+// waits -- for its loads and for its own launch -- far more than it computes: 0.16 -> 0.08 ms per 128 metric frames).
+#define DCB_GROUPS 4                                  // groups of 256 blocks per workgroup = waves
+__global__ __launch_bounds__(64 * DCB_GROUPS) void k_enc_dcbits(const EncArgs a)
 {
 	__shared__ uint8_t dcsz[2][16];
-	__shared__ unsigned scratch[4];
+	__shared__ uint32_t ktab[JH_MAX_MCU_BLOCKS];
 	const JhEncodeWork &w = a.w;
 	const JhGeom &g = a.g;
 	const int f = blockIdx.y;
 	if (threadIdx.x < 32) {
 		dcsz[threadIdx.x >> 4][threadIdx.x & 15] = (uint8_t)(w.codes[(size_t)f * 4 + (threadIdx.x >> 4)].code[threadIdx.x & 15] & 0xffu);
 	}
+	if (threadIdx.x >= 64 && threadIdx.x < 64 + g.B) {
+		ktab[threadIdx.x - 64] = make_ktab(g, threadIdx.x - 64);
+	}
 	__syncthreads();
-	const int blk = blockIdx.x * 256 + threadIdx.x;
+	const int grp = blockIdx.x * DCB_GROUPS + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+	if (grp >= w.nwg) {
+		return;
+	}
 	const uint32_t *acdc = w.acdc + (size_t)f * g.nblk;
-	unsigned bits = 0, err = 0;
-	if (blk < g.nblk) {
-		const uint32_t r = acdc[blk];
-		const unsigned acbits = r & 0xffffu;
-		const int comp = g.blk_comp[blk % g.B];
-		const int diff = ((int)r >> 16) - dc_predictor_info(acdc, blk, g, w.restart_interval);
-		if (diff < -2047 || diff > 2047) {
-			err |= JH_EST_DC_RANGE;                        // assert (encoder.c:447)
+	const int ri = w.restart_interval;
+	const unsigned B = (unsigned)g.B;
+	const unsigned magic = 0xffffffffu / B + 1u;          // blk / B = umulhi(blk, magic) for blk < 2^28 (1 < B <= 10)
+	unsigned bits = 0;
+#pragma unroll
+	for (int j = 0; j < 4; ++j) {
+		const int blk = grp * 256 + j * 64 + lane;
+		if (blk < g.nblk) {
+			const uint32_t r = acdc[blk];
+			const unsigned acbits = r & 0xffffu;
+			const int mcu = B == 1 ? blk : (int)__umulhi((unsigned)blk, magic), k = blk - mcu * (int)B;
+			const uint32_t kt = ktab[k];
+			int pred = 0;
+			if (KT_INNER(kt) || (mcu != 0 && !(ri > 0 && mcu % ri == 0))) {
+				pred = (int)acdc[blk - (int)KT_BACK(kt)] >> 16;
+			}
+			const int diff = ((int)r >> 16) - pred;
+			unsigned e = 0;
+			if (diff < -2047 || diff > 2047) {
+				e |= JH_EST_DC_RANGE;                      // assert (encoder.c:447)
+			}
+			const int dcat = category(diff) & 15;
+			const unsigned ds = dcsz[KT_TD(kt)][dcat];
+			if (ds == 0 || acbits == JH_ACBITS_NOCODE) {
+				e |= JH_EST_NO_CODE;                       // value_to_vlc() == -1 (huffman.c:252)
+			}
+			const unsigned mine = ds + (unsigned)dcat + (acbits == JH_ACBITS_NOCODE ? 0u : acbits);
+			w.bitlen[(size_t)f * g.nblk + blk] = (uint16_t)mine;
+			bits += mine;
+			if (e) {
+				atomicOr(&w.state[f].status, e);
+				// inside a block the range test comes first (encoder.c:447 before write_block)
+				atomicMax(&w.state[f].first_err, ~((uint32_t)blk * 2u + ((e & JH_EST_DC_RANGE) ? 0u : 1u)));
+			}
 		}
-		const int dcat = category(diff) & 15;
-		const unsigned ds = dcsz[g.Td[comp] & 1][dcat];
-		if (ds == 0 || acbits == JH_ACBITS_NOCODE) {
-			err |= JH_EST_NO_CODE;                         // value_to_vlc() == -1 (huffman.c:252)
-		}
-		bits = ds + (unsigned)dcat + (acbits == JH_ACBITS_NOCODE ? 0u : acbits);
-		w.bitlen[(size_t)f * g.nblk + blk] = (uint16_t)bits;
 	}
-	if (err) {
-		atomicOr(&w.state[f].status, err);
-		// inside a block the range test comes first (encoder.c:447 before write_block)
-		atomicMax(&w.state[f].first_err, ~((uint32_t)blk * 2u + ((err & JH_EST_DC_RANGE) ? 0u : 1u)));
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) {
+		bits += __shfl_down(bits, o, 64);
 	}
-	const unsigned total = block_sum(bits, scratch);
-	if (threadIdx.x == 0) {
-		w.wg_bits[(size_t)f * (w.nwg + 1) + blockIdx.x] = total;
+	if (lane == 0) {
+		w.wg_bits[(size_t)f * (w.nwg + 1) + grp] = bits;
 	}
 }
 
@@ -725,25 +770,6 @@ struct PackIn {
 	uint32_t kt;                      // its ktab entry
 	bool have;
 };
-
-// per block k of an MCU: component | tables | where the DC predictor of the block is (encoder.c:443-458)
-#define KT_COMP(t) ((t) & 3u)
-#define KT_TD(t) (((t) >> 2) & 1u)
-#define KT_TA(t) (((t) >> 3) & 1u)
-#define KT_INNER(t) (((t) >> 4) & 1u)     // the predictor is the previous block of the same MCU
-#define KT_LASTK(t) (((t) >> 5) & 31u)    // k == B - 1
-#define KT_BACK(t) ((t) >> 16)            // blocks back to the predictor
-
-__device__ __forceinline__ uint32_t make_ktab(const JhGeom &g, int k)
-{
-	const int comp = g.blk_comp[k];
-	const int firstk = g.comp_first[comp];
-	const int lastk = firstk + g.H[comp] * g.V[comp] - 1;
-	const bool inner = k > firstk;
-	const int back = inner ? 1 : k + g.B - lastk;
-	return (uint32_t)comp | ((uint32_t)(g.Td[comp] & 1) << 2) | ((uint32_t)(g.Ta[comp] & 1) << 3) |
-	       ((uint32_t)inner << 4) | ((uint32_t)(k == g.B - 1) << 5) | ((uint32_t)back << 16);
-}
 
 // ktab lives in LDS: reading it does not wait for the global loads in flight
 __device__ __forceinline__ void pack_fetch(const EncArgs &a, const uint32_t *ktab, int f, int grp, int tid, PackIn &in)
@@ -1128,7 +1154,7 @@ int jh_launch_enc_entropy(const JhEncodeWork &w, const JhGeom &g, hipStream_t s,
 	a.g = g;
 	if (acbits_ready) {
 		JH_T_BEGIN(th, "k_enc_dcbits", s);
-		hipLaunchKernelGGL(k_enc_dcbits, dim3(w.nwg, w.nframes), dim3(256), 0, s, a);
+		hipLaunchKernelGGL(k_enc_dcbits, dim3((w.nwg + DCB_GROUPS - 1) / DCB_GROUPS, w.nframes), dim3(64 * DCB_GROUPS), 0, s, a);
 		JH_T_END(th, s);
 	} else {
 		JH_T_BEGIN(th, "k_enc_bitlen", s);
