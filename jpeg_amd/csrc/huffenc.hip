@@ -74,6 +74,14 @@ __device__ __forceinline__ int category(int c)
 	return 32 - __clz(m);             // __clz(0) = 32
 }
 
+// leading bits of v that equal its sign bit, the sign bit included (v is neither 0 nor -1)
+__device__ __forceinline__ int sign_bits(int v)
+{
+	int n;
+	asm("v_ffbh_i32 %0, %1" : "=v"(n) : "v"(v));
+	return n;
+}
+
 // encode_extra (coeffs.c:76-83)
 __device__ __forceinline__ unsigned extra_bits(int c, int cat)
 {
@@ -826,7 +834,11 @@ __device__ __forceinline__ void pack_fetch(const EncArgs &a, const uint32_t *kta
 // previous nonzero) and ORs its code words into an LDS image of the group's bit range.
 __global__ __launch_bounds__(256) void k_enc_pack(const EncArgs a)
 {
-	__shared__ uint32_t codes[4][256];
+	// per table id and symbol: the code word moved up by the symbol's category -- room for the extra bits -- and the
+	// bits of the two together (a look-up gives both at once; behind each table a few entries of room: a category
+	// of 16, which only a frame that has failed already can have, reads there)
+	__shared__ uint2 actab[2][256 + 16];
+	__shared__ uint2 dctab[2][16 + 16];
 	__shared__ unsigned scratch[4];
 	__shared__ __align__(16) uint32_t win[WIN_WORDS + 4];      // + sink
 	__shared__ uint32_t stage[256 * ST_STRIDE];
@@ -849,8 +861,14 @@ __global__ __launch_bounds__(256) void k_enc_pack(const EncArgs a)
 	PackIn in;
 	pack_fetch(a, ktab, f, blockIdx.x, tid, in);
 #pragma unroll
-	for (int j = 0; j < 4; ++j) {
-		codes[j][tid] = w.codes[(size_t)f * 4 + j].code[tid];
+	for (int th = 0; th < 2; ++th) {
+		const unsigned cat = (unsigned)tid & 15u;
+		const uint32_t e = w.codes[(size_t)f * 4 + 2 + th].code[tid];
+		actab[th][tid] = make_uint2((e >> 8) << cat, (e & 0xffu) + cat);
+		if (tid < 16) {
+			const uint32_t d = w.codes[(size_t)f * 4 + th].code[tid];
+			dctab[th][tid] = make_uint2((d >> 8) << cat, (d & 0xffu) + cat);
+		}
 	}
 	for (int i = tid; i < WIN_WORDS / 4; i += 256) {
 		reinterpret_cast<int4 *>(win)[i] = make_int4(0, 0, 0, 0);
@@ -910,8 +928,8 @@ __global__ __launch_bounds__(256) void k_enc_pack(const EncArgs a)
 		const int16_t *mine = reinterpret_cast<const int16_t *>(stage + lb * ST_STRIDE);
 		const unsigned long long nzac = nzmap[lb] & ~1ull;
 		const int diff = phave ? (int)mine[0] - bpred[lb] : 0;
-		const uint32_t *cd = codes[0 * 2 + ((inf >> 20) & 1u)];
-		const uint32_t *ca = codes[1 * 2 + ((inf >> 21) & 1u)];
+		const uint2 *cd = dctab[(inf >> 20) & 1u];
+		const uint2 *ca = actab[(inf >> 21) & 1u];
 
 		const uint32_t wfirst = r0 >> 5, wlast = r1 > r0 ? (r1 - 1) >> 5 : wfirst;
 		for (uint32_t wbase = wfirst; wbase <= wlast && r1 > r0; wbase += WIN_WORDS) {
@@ -921,18 +939,28 @@ __global__ __launch_bounds__(256) void k_enc_pack(const EncArgs a)
 			if (phave && plen && (unsigned long long)start + plen > lo_bit && start < hi_bit) {
 				// a symbol (at most 31 bits) is ORed into the two words it can touch; words outside this
 				// pass's window go to the sink behind it.  No accumulator, no branch.
-				uint32_t pos = start;
+				// (positions count from the window's first bit -- a multiple of 32, and a block is never more than the
+				// group's bits away from it: a signed number of bits.  The word's byte offset is taken with an arithmetic
+				// shift, so that a word in front of the window is a huge unsigned number and goes to the sink, while the
+				// word behind the last one in front is 0: a symbol across the window's start leaves its tail there.)
+				int pos = (int)(start - lo_bit);
 				auto put = [&](unsigned code, unsigned len) {
-					const unsigned long long v = (unsigned long long)code << ((64u - (pos & 31u) - len) & 63u);
-					const uint32_t rel = (pos >> 5) - wbase;   // unsigned: words before the window wrap to huge
-					atomicOr(&win[min(rel, (uint32_t)WIN_WORDS)], (uint32_t)(v >> 32));
-					atomicOr(&win[min(rel + 1u, (uint32_t)WIN_WORDS)], (uint32_t)v);
-					pos += len;
+					const unsigned long long v = (unsigned long long)code << ((64u - ((unsigned)pos & 31u) - len) & 63u);
+					const uint32_t at = (uint32_t)(pos >> 3) & ~3u;
+					unsigned char *w8 = reinterpret_cast<unsigned char *>(win);
+					atomicOr(reinterpret_cast<uint32_t *>(w8 + min(at, (uint32_t)WIN_WORDS * 4u)), (uint32_t)(v >> 32));
+					atomicOr(reinterpret_cast<uint32_t *>(w8 + min(at + 4u, (uint32_t)WIN_WORDS * 4u)), (uint32_t)v);
+					pos += (int)len;
 				};
-				const int dcat = category(diff) & 15;
-				const uint32_t dcode = cd[dcat];               // write_dc (coeffs.c:110-126)
-				put(((dcode >> 8) << dcat) | extra_bits(diff, dcat), (dcode & 0xffu) + dcat);
+				// encode_cat / encode_extra (coeffs.c:56-83) in one go: a negative value's extra bits are those of
+				// value - 1, and the category is what is left of 32 bits behind the leading sign bits of THAT
+				const int ds = diff + (diff >> 31);
+				const int dcat = diff ? 32 - sign_bits(ds) : 0;
+				const uint2 dcode = cd[dcat];                  // write_dc (coeffs.c:110-126)
+				put(dcode.x | __builtin_amdgcn_ubfe((unsigned)ds, 0u, (unsigned)dcat), dcode.y);
 				// write_ac (coeffs.c:164-194); the next nonzero coefficient is read while this one is emitted
+				// (behind the last nonzero coefficient, coefficient 63 is read for nothing.  ORing bit 63 into the map
+				// instead of the select costs 3 %, and so does walking the map as two 32-bit halves: measured)
 				unsigned long long m = nzac;
 				int prev = 0;
 				int k = m ? __builtin_ctzll(m) : 63;
@@ -944,20 +972,21 @@ __global__ __launch_bounds__(256) void k_enc_pack(const EncArgs a)
 					const int r = k - prev - 1;
 					prev = k;
 					if (r > 15) {
-						const uint32_t z = ca[0xf0];           // ZRL
+						const uint2 z = ca[0xf0];              // ZRL
 						for (int q = r >> 4; q > 0; --q) {
-							put(z >> 8, z & 0xffu);
+							put(z.x, z.y);
 						}
 					}
-					const int cat = category(c);
-					const uint32_t e = ca[((r & 15) << 4) | (cat & 15)];
-					put(((e >> 8) << cat) | extra_bits(c, cat), (e & 0xffu) + cat);
+					const int cs = c + (c >> 31);              // c is not zero here
+					const int cat = 32 - sign_bits(cs);
+					const uint2 e = ca[((r & 15) << 4) + cat];
+					put(e.x | __builtin_amdgcn_ubfe((unsigned)cs, 0u, (unsigned)cat), e.y);
 					k = kn;
 					c = cn;
 				}
 				if (prev != 63) {
-					const uint32_t e = ca[0];                  // EOB
-					put(e >> 8, e & 0xffu);
+					const uint2 e = ca[0];                     // EOB
+					put(e.x, e.y);
 				}
 				if (ppad) {
 					put((1u << ppad) - 1u, ppad);              // flush_bits at the end of a restart interval
