@@ -1672,6 +1672,7 @@ struct jpeg_hip_encoder {
 	JhQuant *d_quant = nullptr;
 	int16_t *d_coefs = nullptr;
 	JhHuffEnc *d_codes = nullptr;
+	JhRunTab *d_runtab = nullptr;         // [frame]: the pixel kernel's price tables (default tables only)
 	JhDevSpec *d_specs = nullptr;
 	uint8_t *d_hdr_parts = nullptr;   // header bytes around the DHT segments (optimised mode builds headers on the device)
 	uint32_t *d_hist = nullptr, *d_wg_bits = nullptr, *d_us = nullptr, *d_chunk_ff = nullptr, *d_hdr_len = nullptr;
@@ -1706,7 +1707,7 @@ struct jpeg_hip_encoder {
 
 	void release()
 	{
-		hipFree(d_quant); hipFree(d_coefs); hipFree(d_codes); hipFree(d_hist); hipFree(d_wg_bits);
+		hipFree(d_quant); hipFree(d_coefs); hipFree(d_codes); hipFree(d_runtab); hipFree(d_hist); hipFree(d_wg_bits);
 		hipFree(d_us); hipFree(d_chunk_ff); hipFree(d_hdr_len); hipFree(d_bitlen); hipFree(d_nzmap); hipFree(d_acdc); hipFree(d_out); hipFree(d_state);
 		hipFree(d_ivl_raw); hipFree(d_ivl_padsum); hipFree(d_ivl_eb); hipFree(d_specs); hipFree(d_hdr_parts);
 		hipFree(d_soff); hipFree(d_slen); hipFree(d_pack);
@@ -1718,7 +1719,7 @@ struct jpeg_hip_encoder {
 		d_soff = nullptr; d_slen = nullptr; h_state = nullptr; h_hdr_len = h_slen = nullptr; h_soff = nullptr;
 		d_specs = nullptr; d_hdr_parts = nullptr;
 		d_ivl_raw = d_ivl_padsum = d_ivl_eb = nullptr;
-		d_quant = nullptr; d_coefs = nullptr; d_codes = nullptr; d_hist = d_wg_bits = d_us = d_chunk_ff = d_hdr_len = nullptr;
+		d_quant = nullptr; d_coefs = nullptr; d_codes = nullptr; d_runtab = nullptr; d_hist = d_wg_bits = d_us = d_chunk_ff = d_hdr_len = nullptr;
 		d_bitlen = nullptr; d_nzmap = nullptr; d_acdc = nullptr; d_out = nullptr; d_state = nullptr;
 	}
 };
@@ -1906,6 +1907,7 @@ static int encoder_configure(jpeg_hip_encoder *enc, int nframes, int X, int Y, i
 	HIPCHK(hipMalloc((void **)&enc->d_quant, nframes * sizeof(JhQuant)));
 	HIPCHK(hipMalloc((void **)&enc->d_coefs, (size_t)nframes * g.nblk * 64 * sizeof(int16_t)));
 	HIPCHK(hipMalloc((void **)&enc->d_codes, (size_t)nframes * 4 * sizeof(JhHuffEnc)));
+	HIPCHK(hipMalloc((void **)&enc->d_runtab, (size_t)nframes * sizeof(JhRunTab)));
 	HIPCHK(hipMalloc((void **)&enc->d_hist, (size_t)nframes * 4 * 257 * sizeof(uint32_t)));
 	HIPCHK(hipMalloc((void **)&enc->d_wg_bits, (size_t)nframes * (w.nwg + 1) * sizeof(uint32_t)));
 	HIPCHK(hipMalloc((void **)&enc->d_us, (size_t)nframes * w.us_stride));
@@ -2043,7 +2045,7 @@ static int encoder_run(jpeg_hip_encoder *enc, const void *d_samples, size_t fram
 	// default tables: the codes are known, and the pixel kernel counts every block's AC bits while it holds the block
 	const bool acbits = !enc->prm.optimize;
 	if (jh_launch_encode_pixels(g, enc->nframes, d_samples, frame_stride, enc->d_quant, enc->d_coefs, enc->d_nzmap, enc->d_acdc,
-	                            acbits ? enc->d_codes : nullptr, enc->d_state, s, enc->float_tap)) {
+	                            acbits ? enc->d_codes : nullptr, enc->d_runtab, enc->d_state, s, enc->float_tap)) {
 		return RET_FAILURE_LOGIC_ERROR;
 	}
 	enc->timer.end(s);
@@ -2649,6 +2651,7 @@ extern "C" int jpeg_hip_encode_noalloc(int device, const jpeg_hip_params *params
 	su.off_hdr = (uint32_t)take(sizeof su.hdr);
 	su.off_specs = (uint32_t)take(4 * sizeof(JhDevSpec));
 	su.off_codes = (uint32_t)take(4 * sizeof(JhHuffEnc));
+	const size_t off_runtab = take(sizeof(JhRunTab));
 	const size_t off_hist = take(4 * 257 * sizeof(uint32_t));
 	const size_t off_chunk_ff = take((JH_NOALLOC_BYTES / 4096) * sizeof(uint32_t));
 	const size_t off_wg_bits = take((size_t)(w.nwg + 1) * sizeof(uint32_t));
@@ -2723,7 +2726,8 @@ extern "C" int jpeg_hip_encode_noalloc(int device, const jpeg_hip_params *params
 		return RET_FAILURE_LOGIC_ERROR;
 	}
 	if (jh_launch_encode_pixels(g, 1, d_samples, raw, reinterpret_cast<const JhQuant *>(base + su.off_quant),
-	                            reinterpret_cast<int16_t *>(base + off_coefs), w.nzmap, w.acdc, params->optimize ? nullptr : w.codes, w.state, s)) {
+	                            reinterpret_cast<int16_t *>(base + off_coefs), w.nzmap, w.acdc, params->optimize ? nullptr : w.codes,
+	                            reinterpret_cast<JhRunTab *>(base + off_runtab), w.state, s)) {
 		return RET_FAILURE_LOGIC_ERROR;
 	}
 	if (params->optimize) {
@@ -3057,7 +3061,7 @@ extern "C" int jpeg_hip_encode_pixels(int device, const jpeg_hip_frame_desc *fra
 		if (!d_in || hipMemcpy(d_in, samples, body, hipMemcpyHostToDevice) != hipSuccess ||
 		    hipMemset(enc->d_state, 0, sizeof(JhEncState)) != hipSuccess) {
 			err = RET_FAILURE_MEMORY_ALLOCATION;
-		} else if (jh_launch_encode_pixels(g, 1, d_in, body, enc->d_quant, enc->d_coefs, nullptr, nullptr, nullptr, enc->d_state, nullptr) ||
+		} else if (jh_launch_encode_pixels(g, 1, d_in, body, enc->d_quant, enc->d_coefs, nullptr, nullptr, nullptr, nullptr, enc->d_state, nullptr) ||
 		           hipMemcpy(&st0, enc->d_state, sizeof st0, hipMemcpyDeviceToHost) != hipSuccess) {
 			err = RET_FAILURE_LOGIC_ERROR;
 		} else if (st0.status & JH_EST_NO_CODE) {

@@ -117,12 +117,23 @@ int jh_launch_decode_pixels(const JhGeom &g, int nframes, const int16_t *coefs, 
 // read by k_enc_dcbits (DC symbol + sums) and by k_enc_pack instead of a second look at the coefficients.
 #define JH_ACBITS_NOCODE 0xffffu
 
+// What the AC symbols of a block cost with a frame's codes, as stage 5 of the pixel kernel looks it up: per AC table id
+// (0 / 1), zero run 0 ... 63 and category, the size of the symbol's code plus its extra bits plus (run >> 4) times
+// the size of ZRL (0x4000 and up: a symbol without a code, value_to_vlc == -1); fix[id] = sizes of EOB and ZRL.
+// Made once per run() from the frames' codes (k_enc_runtab) instead of by every workgroup of the pixel kernel.
+struct JhRunTab {
+	uint16_t run[2][64][16];
+	uint16_t fix[2][2];
+	uint16_t pad[4];
+};
+
 // state: NULL, or the frames' states: for P > 12 a coefficient beyond 16 bits sets JH_EST_NO_CODE there.
 // codes: NULL, or the frames' codes ([frame][4]): the kernel then also fills nzmap[] / acdc[] ([frame][nblk]) with
-// the AC code sizes of codes[frame * 4 + 2 + Ta]
+// the AC code sizes of codes[frame * 4 + 2 + Ta], through runtab[frame] (device memory for the kernel's tables)
 int jh_launch_encode_pixels(const JhGeom &g, int nframes, const void *in, size_t frame_stride,
                             const JhQuant *quant_raster, int16_t *coefs, unsigned long long *nzmap, uint32_t *acdc,
-                            const JhHuffEnc *codes, struct JhEncState *state, hipStream_t stream, float *tap = nullptr);
+                            const JhHuffEnc *codes, JhRunTab *runtab, struct JhEncState *state, hipStream_t stream,
+                            float *tap = nullptr);
 // tap (both launchers): NULL, or device memory that receives the float stage boundary of the reference the kernel
 // crosses -- decode: frame->data behind frame_to_rgb (frame.c:188-244), [frame][Y][X][1 or 3]; encode: the component
 // planes behind transform_frame_to_components (frame.c:84-132), [frame][planes of by*8 x bx*8] -- for the stage tests

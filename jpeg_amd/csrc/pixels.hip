@@ -588,7 +588,7 @@ struct EncPixArgs {
 	unsigned long long *nzmap; // [frame][nblk] (with codes)
 	uint32_t *acdc;            // [frame][nblk] (with codes)
 	JhEncState *state;         // [frame], or NULL: a coefficient that does not fit 16 bits is reported there
-	const JhHuffEnc *codes;    // [frame][4] the codes in force for the frame, or NULL
+	const JhRunTab *runtab;    // [frame] what AC symbols cost with the codes in force for the frame, or NULL
 	float *tap;                // NULL, or [frame][component planes, by*8 rows of bx*8]: the planes behind the down-sampling,
 	                           // before the level shift (stage tests)
 	TileLayout L;
@@ -787,19 +787,49 @@ __device__ __forceinline__ unsigned nz_octet(const int4 v)
 // lies behind the blocks' int16 lines and is free once the float planes are dead:
 //   nzm    the blocks' nonzero maps, one byte per octet
 //   pbits  AC bits of the two halves of a block
-//   actab  size + category of every AC symbol per table id (0: never looked up, 0x4000: no code)
 //   acfix  sizes of EOB / ZRL per table id
-//   runtab what a coefficient of category c behind a zero run of r = 0 ... 63 costs: actab[r & 15][c] plus
-//          (r >> 4) times the size of ZRL -- one look-up per nonzero coefficient, nothing to mask or multiply
+//   runtab what a coefficient of category c behind a zero run of r = 0 ... 63 costs: size + category of the symbol
+//          (r & 15, c) plus (r >> 4) times the size of ZRL -- one look-up per nonzero coefficient, nothing to mask
+//          or multiply.  A copy of the frame's JhRunTab (k_enc_runtab makes it, once per run(): built here, by every
+//          workgroup from the codes, the two tables cost two barriers and 0.2 of the kernel's 2.8 ms).
 struct Stage5 {
 	unsigned long long nzm[128];
 	unsigned pbits[2][128];
-	uint16_t actab[2][256];
 	uint16_t acfix[2][2];
 	uint16_t pad[4];
 	__attribute__((aligned(16))) uint16_t runtab[2][64][16];
 };
 #define STAGE5_OFF (TILE_BLOCKS * LINE_I16 * 2)             // bytes: behind the lines of a full tile
+
+// JhRunTab of every frame from its AC codes (codes[frame * 4 + 2 + id]): one workgroup per frame
+__global__ __launch_bounds__(256) void k_enc_runtab(const JhHuffEnc *codes, JhRunTab *out)
+{
+	__shared__ __attribute__((aligned(16))) uint16_t actab[2][256];    // size + category per symbol (0: never looked up)
+	__shared__ uint16_t acfix[2][2];
+	const int f = blockIdx.x, tid = threadIdx.x;
+	for (int i = tid; i < 2 * 256; i += 256) {
+		const int th = i >> 8, sym = i & 255, cat = sym & 15;
+		const unsigned size = codes[(size_t)f * 4 + 2 + th].code[sym] & 0xffu;
+		actab[th][sym] = (uint16_t)(cat == 0 ? 0u : (size ? size + (unsigned)cat : 0x4000u));
+		if (sym == 0x00) {
+			acfix[th][0] = (uint16_t)(size ? size : 0x4000u);
+		}
+		if (sym == 0xf0) {
+			acfix[th][1] = (uint16_t)(size ? size : 0x4000u);
+		}
+	}
+	__syncthreads();
+	// thread = (table, run, eight categories), one 16-byte read, one 16-byte write.  A flagged entry (0x4000) stays
+	// flagged: at most 3 * 16 is added.
+	const int th = tid >> 7, run = (tid >> 1) & 63, half = tid & 1;
+	const unsigned z = (unsigned)(run >> 4) * acfix[th][1], zz = z | (z << 16);
+	uint4 v = *reinterpret_cast<const uint4 *>(&actab[th][((run & 15) << 4) + half * 8]);
+	v.x += zz; v.y += zz; v.z += zz; v.w += zz;            // no carry between the halves: every entry < 0x8000
+	*reinterpret_cast<uint4 *>(&out[f].run[th][run][half * 8]) = v;
+	if (tid < 4) {
+		(&out[f].fix[0][0])[tid] = (&acfix[0][0])[tid];
+	}
+}
 
 // NF = 1: one plane, no sub-sampling.  NF = 3: luma at full resolution, both chroma planes
 // down-sampled SX x SY (what read_image() sets up: luma H x V, chroma 1 x 1; encoder.c:109-146).
@@ -839,6 +869,8 @@ __global__ __launch_bounds__(256) void k_encode_pixels(const EncPixArgs a)
 		e[2] = quant_reciprocal(d);
 	}
 	stage_ktab(kt, L, B, tid);
+	uint4 rt = make_uint4(0, 0, 0, 0);                // stage 5's tables, 16 bytes per thread
+	unsigned rfix = 0;
 
 	// ---- 1: (row group, 4 pixels): samples -> float, RGB -> YCbCr, box mean, level shift --------
 	{
@@ -949,6 +981,12 @@ __global__ __launch_bounds__(256) void k_encode_pixels(const EncPixArgs a)
 				atomicOr(&a.state[f].status, (uint32_t)JH_EST_NO_CODE);
 			}
 		}
+		// stage 5's tables: asked for here -- the transforms, which need every register, are done -- and in hand
+		// two barriers on
+		if (a.runtab) {
+			rt = reinterpret_cast<const uint4 *>(&a.runtab[f].run[0][0][0])[tid];
+			rfix = (&a.runtab[f].fix[0][0])[tid & 3];
+		}
 		__syncthreads();                              // every column has been read: the blocks' int16 lines go over the planes
 		uint16_t *zp[8];                              // this thread's places in the line of its block of round 0
 #pragma unroll
@@ -978,38 +1016,21 @@ __global__ __launch_bounds__(256) void k_encode_pixels(const EncPixArgs a)
 			if (t < ntask) {
 				const int4 v = *reinterpret_cast<const int4 *>(reinterpret_cast<const int16_t *>(stg) + (t >> 3) * LINE_I16 + (t & 7) * 8);
 				dst[t] = v;
-				if (a.codes) {
+				if (a.runtab) {
 					reinterpret_cast<uint8_t *>(s5.nzm)[t] = (uint8_t)nz_octet(v);
 				}
 			}
 		}
 	}
-	if (!a.codes) {
+	if (!a.runtab) {
 		return;
 	}
 #ifdef X_SKIP5
 	return;
 #endif
-	for (int i = tid; i < 2 * 256; i += 256) {
-		const int th = i >> 8, sym = i & 255, cat = sym & 15;
-		const unsigned size = a.codes[(size_t)f * 4 + 2 + th].code[sym] & 0xffu;
-		s5.actab[th][sym] = (uint16_t)(cat == 0 ? 0u : (size ? size + (unsigned)cat : 0x4000u));
-		if (sym == 0x00) {
-			s5.acfix[th][0] = (uint16_t)(size ? size : 0x4000u);
-		}
-		if (sym == 0xf0) {
-			s5.acfix[th][1] = (uint16_t)(size ? size : 0x4000u);
-		}
-	}
-	__syncthreads();
-	{
-		// runtab from actab: thread = (table, run, eight categories), one 16-byte read, one 16-byte write.  A flagged
-		// entry (0x4000) stays flagged: at most 3 * 16 is added.
-		const int th = tid >> 7, run = (tid >> 1) & 63, half = tid & 1;
-		const unsigned z = (unsigned)(run >> 4) * s5.acfix[th][1], zz = z | (z << 16);
-		uint4 v = *reinterpret_cast<const uint4 *>(&s5.actab[th][((run & 15) << 4) + half * 8]);
-		v.x += zz; v.y += zz; v.z += zz; v.w += zz;        // no carry between the halves: every entry < 0x8000
-		*reinterpret_cast<uint4 *>(&s5.runtab[th][run][half * 8]) = v;
+	reinterpret_cast<uint4 *>(&s5.runtab[0][0][0])[tid] = rt;  // 256 threads x 16 bytes = the two tables
+	if (tid < 4) {
+		(&s5.acfix[0][0])[tid] = (uint16_t)rfix;
 	}
 	__syncthreads();
 
@@ -1070,7 +1091,7 @@ __global__ __launch_bounds__(256) void k_encode_pixels(const EncPixArgs a)
 
 int jh_launch_encode_pixels(const JhGeom &g, int nframes, const void *in, size_t frame_stride,
                             const JhQuant *quant_raster, int16_t *coefs, unsigned long long *nzmap, uint32_t *acdc,
-                            const JhHuffEnc *codes, JhEncState *state, hipStream_t stream, float *tap)
+                            const JhHuffEnc *codes, JhRunTab *runtab, JhEncState *state, hipStream_t stream, float *tap)
 {
 	EncPixArgs a;
 	a.tap = tap;
@@ -1080,13 +1101,16 @@ int jh_launch_encode_pixels(const JhGeom &g, int nframes, const void *in, size_t
 	a.coefs = coefs;
 	a.nzmap = nzmap;
 	a.acdc = acdc;
-	a.codes = nzmap && acdc ? codes : nullptr;
+	a.runtab = nzmap && acdc && codes ? runtab : nullptr;
+	if (a.runtab) {
+		hipLaunchKernelGGL(k_enc_runtab, dim3(nframes), dim3(256), 0, stream, codes, runtab);
+	}
 	a.state = g.P > 12 ? state : nullptr;
 	make_layout(g, &a.L);
 	a.g = g;
 	dim3 grid((g.m_x + a.L.G - 1) / a.L.G, g.m_y, nframes);
 	size_t lds = (size_t)a.L.lds_floats * sizeof(float);
-	if (a.codes && lds < STAGE5_OFF + sizeof(Stage5)) {
+	if (a.runtab && lds < STAGE5_OFF + sizeof(Stage5)) {
 		lds = STAGE5_OFF + sizeof(Stage5);                 // small tiles: room for stage 5 behind the lines
 	}
 	if (g.sample_bytes != 1 && g.sample_bytes != 2) {
