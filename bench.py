@@ -629,6 +629,44 @@ def main():
         res["kernel_ms"] = {k: round(v, 4) for k, v in sorted(allk.items(), key=lambda kv: -kv[1])}
         res["pipeline_hbm_frac"] = {"decode": round(alg_bytes / (t_d / args.steps) / 1e9 / HBM_PEAK_GBS, 5),
                                     "encode": round(alg_bytes / (t_e / args.steps) / 1e9 / HBM_PEAK_GBS, 5)}
+    if rank == 0 and world == 1 and not args.no_workloads:
+        # ---- the reference's own use: ONE image per call (decoder in.jpg out.ppm / encoder in.ppm out.jpg).  Host
+        # inclusive on the side that is small: codestream from host memory -> samples in HBM (prepare + run + sync);
+        # samples in HBM -> codestream in host memory (run + sync + copy).  Objects kept between calls.
+        d1 = binding.Decoder(dev)
+        e1 = binding.Encoder(dev)
+        e1.configure(1, cfg["X"], cfg["Y"], cfg["nc"], cfg["P"], cfg["H"], cfg["V"], cfg["q"], cfg["opt"])
+        one = samples[:1]
+
+        def dec_one():
+            d1.prepare(jpgs[:1])
+            o1 = d1.run()
+            assert d1.sync() == [0]
+            return o1
+
+        def enc_one():
+            e1.run(one)
+            st1, ln1 = e1.sync()
+            assert st1 == [0]
+            return e1.jpeg(0, ln1[0])
+
+        dec_one()
+        assert enc_one() == jpgs[0]
+        reps = 20
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            dec_one()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            enc_one()
+        t2 = time.perf_counter()
+        res["single_frame_ms"] = {"decode_jpg_in_host_memory_to_samples_in_hbm": round((t1 - t0) / reps * 1e3, 3),
+                                  "encode_samples_in_hbm_to_jpg_in_host_memory": round((t2 - t1) / reps * 1e3, 3),
+                                  "frame": "4K 4:2:0 q90, one frame per call, objects kept between calls"}
+        d1.close()
+        e1.close()
     cpu_imgs = [host_image(samples, f, cfg) for f in range(4)] if rank == 0 and world == 1 and not args.no_cpu else None
     cpu_jpgs = jpgs[:4]
     enc.close()
