@@ -25,7 +25,8 @@
 #include "codestream.hpp"
 #include "kernels.hpp"
 
-#define JH_MAX_PASSES 8               // scans per frame the decoder takes (each is a pass of the Huffman kernels)
+#define JH_MAX_PASSES 32              // scans per frame the decoder takes (each is a pass of the Huffman kernels with
+                                      // buffers of its own; the reference takes any number, decoder.c:593-601)
 
 #define HIPCHK(call)                                                                         \
 	do {                                                                                     \

@@ -763,6 +763,42 @@ def _scan_segments(jpg):
     return out
 
 
+def test_a_dozen_scans(hip, oracle):
+    """The reference reads as many scans as the file holds (decoder.c:593-601); the decoder keeps a pass per scan,
+    up to 32.  Luma coded ten times over (scans of a second and a third image taking turns) behind the three
+    per-component scans of the first: 13 scans; 33 scans are refused as unsupported."""
+    imgs = [synth_image(176, 112, 3, 8, seed=61 + i) for i in range(3)]
+    files = []
+    for im in imgs:
+        err, j = oracle.encode_scans(im, P=8, H=2, V=2, q=80, optimize=0, restart_interval=0, redefine=0, split=0)
+        assert err == 0
+        files.append(j)
+    segs = [_scan_segments(j) for j in files]
+    ja, sa = files[0], segs[0]
+    head, tail = ja[:sa[-1][1]], ja[sa[-1][1]:]
+    luma = [files[k][segs[k][0][0]:segs[k][0][1]] for k in (1, 2)]
+    jpg = head + b"".join(luma[i % 2] for i in range(10)) + tail
+    assert len(_scan_segments(jpg)) == 13
+    oerr, opx, oinfo = oracle.decode(jpg)
+    assert oerr == 0
+    d = hip.Decoder()
+    try:
+        d.prepare([jpg, jpg])                            # (the frames of a batch have their scans in common)
+        out = d.run()
+        assert d.sync() == [0, 0]
+        _assert_coefs(d.coefficients(1), oinfo)
+        px = d.to_arrays(out)
+        assert np.array_equal(px[0], opx) and np.array_equal(px[1], opx)
+        assert not np.array_equal(opx, oracle.decode(ja)[1])
+        # the last luma scan is image 2's (i = 9 is odd: luma[1]): luma of that image, chroma of the first
+        many = head + b"".join(luma[i % 2] for i in range(30)) + tail
+        assert len(_scan_segments(many)) == 33
+        with pytest.raises(hip.JpegError):
+            d.prepare([many])
+    finally:
+        d.close()
+
+
 def test_components_coded_more_than_once(hip, oracle):
     """decoder.c:593-601 reads whatever scans come; read_block() stores every coefficient of a block it reads
     (coeffs.c:222-229), so a component that is coded again is simply written again.  Files made by splicing scans

@@ -243,6 +243,22 @@ def test_components_coded_more_than_once(oracle, reference):
             assert _same_coefs(io, ir) and np.array_equal(po, pr)
 
 
+def test_a_dozen_scans(oracle, reference):
+    """Thirteen scans in one file (the construction of tests/test_gpu_parity.py::test_a_dozen_scans): the reference
+    reads as many as there are (decoder.c:593-601)."""
+    imgs = [synth_image(176, 112, 3, 8, seed=61 + i) for i in range(3)]
+    files = [oracle.encode_scans(im, P=8, H=2, V=2, q=80, optimize=0, restart_interval=0, redefine=0, split=0)[1] for im in imgs]
+    segs = [_scan_segments(j) for j in files]
+    ja, sa = files[0], segs[0]
+    luma = [files[k][segs[k][0][0]:segs[k][0][1]] for k in (1, 2)]
+    jpg = ja[:sa[-1][1]] + b"".join(luma[i % 2] for i in range(10)) + ja[sa[-1][1]:]
+    assert len(_scan_segments(jpg)) == 13
+    eo, po, io = oracle.decode(jpg)
+    er, pr, ir = reference.decode(jpg)
+    assert eo == er == 0
+    assert _same_coefs(io, ir) and np.array_equal(po, pr)
+
+
 def test_sample_precisions_beyond_12_bits(oracle, reference):
     """P 13 ... 16 (frame.c:270-275): the oracle against the compiled reference, both directions, on the
     low-contrast images the reference's DC assert leaves it at such precisions (the GPU test uses the same)."""
