@@ -954,8 +954,14 @@ int orc_decode(const uint8_t *jpg, size_t n, orc_image **img_out, uint8_t **samp
 		goto fail;
 	}
 	memset(&sc, 0, sizeof sc);
+	/* Table ids 2 and 3 with no codes until a DHT segment defines them.  The reference's init_context() never
+	 * fills context->hcode[][2..3] (common.c:90-99 converts the four implicit tables only; the context is
+	 * malloc()ed, decoder.c:665): a scan that names such a table without a DHT reads uninitialised memory there,
+	 * and what it decodes changes from run to run.  On fresh (zero) pages query_code() matches nothing (last_k = 0,
+	 * huffman.c:203-216), read_code() runs on to the end of the data (huffman.c:262-268) -- that reading is taken
+	 * here, and by the HIP path. */
 	for (int tc = 0; tc < 2; ++tc) {
-		for (int th = 0; th < 2; ++th) {
+		for (int th = 0; th < 4; ++th) {
 			hufftab_build(&ht[tc][th], img->htL[tc][th], img->htV[tc][th]);
 		}
 	}

@@ -240,7 +240,8 @@ def test_markers_inside_the_data_followed_by_restart_intervals(hip, oracle):
 def test_streams_the_fuzz_runs_found(hip, oracle):
     """tests/golden/damaged/: streams of tools/fuzz_corrupt.py (seeds 22 and 23) on which the write pass lost the
     blocks of an unfinished MCU to k_coef_tail_clear -- data that ends exactly where a sub-sequence does, and a
-    spurious RSTn whose segment holds nothing decodable behind a segment that ended inside a block."""
+    spurious RSTn whose segment holds nothing decodable behind a segment that ended inside a block; and (seed 202) a scan
+    header that names a Huffman table no DHT segment defined, where it was the ORACLE that had to change."""
     import glob
     import os
     files = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "damaged", "*.jpg")))
@@ -248,6 +249,22 @@ def test_streams_the_fuzz_runs_found(hip, oracle):
     for path in files:
         with open(path, "rb") as fh:
             assert _compare(hip, oracle, fh.read(), os.path.basename(path)) is None
+
+
+def test_scans_that_name_tables_no_dht_defined(hip, oracle):
+    """golden/damaged/undefined_ac_table_in_second_scan.jpg (fuzz seed 202, case 18356: a bit flip in the second SOS
+    header, Ta = 3 for Cb) and its relatives: table ids 2 and 3 without a DHT segment, for the DC or the AC symbols,
+    in the luma scan or the chroma scan.  The reference reads uninitialised memory there (common.c:90-99 converts the
+    implicit tables 0 / 1 only; its output changes from run to run); the oracle and this path take what zero pages
+    give -- no code matches, the restart interval is used up (tests/test_oracle_golden.py has the details)."""
+    import os
+    with open(os.path.join(os.path.dirname(__file__), "golden", "damaged", "undefined_ac_table_in_second_scan.jpg"), "rb") as fh:
+        jpg0 = fh.read()
+    for off in (2867, 2869, 603):                        # Td | Ta of Cb, of Cr (second scan), of Y (first scan)
+        for val in (0x13, 0x12, 0x31, 0x21, 0x33, 0x22, 0x10, 0x01, 0x30, 0x03):
+            b = bytearray(jpg0)
+            b[off] = val
+            assert _compare(hip, oracle, bytes(b), ("undefined table", off, hex(val))) is None
 
 
 def test_data_that_ends_where_a_sub_sequence_ends(hip, oracle):

@@ -136,3 +136,24 @@ def test_k2_optimiser_properties(oracle):
         assert sum(int(L[i]) * 2.0 ** -(i + 1) for i in range(16)) < 1.0
         si, co = oracle.make_codes(L, V)
         assert all(si[s] > 0 for s in idx)
+
+
+def test_a_scan_that_names_a_table_no_dht_defined(oracle):
+    """tests/golden/damaged/undefined_ac_table_in_second_scan.jpg (tools/fuzz_corrupt.py, seed 202, case 18356): a bit
+    flip in the second SOS header makes Cb use AC table 3, which no DHT segment defines.  The reference reads
+    uninitialised memory there (init_context() converts the four implicit tables only, common.c:90-99, and the context
+    is malloc()ed, decoder.c:665) -- its output changes from run to run; on zero pages nothing matches, read_code()
+    runs to the end of each restart interval, and what stays of an interval is the DC difference of its first Cb block
+    (coeffs.c:222).  The oracle takes that reading (and so does the HIP path: test_gpu_damaged.py)."""
+    with open(golden_path("damaged/undefined_ac_table_in_second_scan.jpg"), "rb") as fh:
+        jpg = fh.read()
+    assert jpg[2861:2871] == bytes.fromhex("ffda000a020213031100"[:20])
+    err, px, info = oracle.decode(jpg)
+    assert err == 0
+    cb, cr = info.comps[1]["coef"], info.comps[2]["coef"]
+    assert [int(cb[k][0]) for k in range(6)] == [-9, 0, 0, 0, 0, 0]
+    assert not cr.any()
+    # ri = 3 MCUs of one Cb and one Cr block: only the first Cb block of an interval can hold anything, its DC alone
+    for k in range(len(cb)):
+        assert not cb[k][1:].any()
+        assert k % 3 == 0 or cb[k][0] == 0
