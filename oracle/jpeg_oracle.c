@@ -188,6 +188,9 @@ typedef struct {
 	uint8_t ehufsi[256];      /* 0 = symbol absent */
 	uint16_t ehufco[256];
 	int32_t mincode[17], maxcode[17], valptr[17];  /* canonical decode helpers */
+	int irregular;            /* more codes of some size than the size has room for (a damaged DHT): CODE, 16 bits wide in
+	                           * the reference (huffman.c:91), runs past the size or wraps, the codes of a size are no
+	                           * longer one range, and only query_code()'s own search says what matches */
 } hufftab;
 
 static int hufftab_build(hufftab *h, const uint8_t L[16], const uint8_t V[256])
@@ -211,9 +214,12 @@ static int hufftab_build(hufftab *h, const uint8_t L[16], const uint8_t V[256])
 	int si = h->huffsize[0];
 	for (int p = 0; p < k; ) {
 		while (p < k && h->huffsize[p] == si) {
+			if (code >> si) {
+				h->irregular = 1;
+			}
 			h->huffcode[p++] = (uint16_t)code++;
 		}
-		code <<= 1;
+		code = (code << 1) & 0x1ffff;                   /* (bit 16 kept: "past the size" must stay visible) */
 		si++;
 	}
 
@@ -591,6 +597,15 @@ static int read_symbol(bitr *r, const hufftab *h)
 			return -1;
 		}
 		code = (code << 1) | b;
+		if (h->irregular) {
+			/* query_code() as it is (huffman.c:193-225): the first entry of this size with this code */
+			for (int p = 0; p < h->nsym; ++p) {
+				if (h->huffsize[p] == len && h->huffcode[p] == (uint16_t)code) {
+					return h->huffval[p];
+				}
+			}
+			continue;
+		}
 		if (h->maxcode[len] >= 0 && code >= h->mincode[len] && code <= h->maxcode[len]) {
 			return h->huffval[h->valptr[len] + (code - h->mincode[len])];
 		}

@@ -241,7 +241,8 @@ def test_streams_the_fuzz_runs_found(hip, oracle):
     """tests/golden/damaged/: streams of tools/fuzz_corrupt.py (seeds 22 and 23) on which the write pass lost the
     blocks of an unfinished MCU to k_coef_tail_clear -- data that ends exactly where a sub-sequence does, and a
     spurious RSTn whose segment holds nothing decodable behind a segment that ended inside a block; and (seed 202) a scan
-    header that names a Huffman table no DHT segment defined, where it was the ORACLE that had to change."""
+    header that names a Huffman table no DHT segment defined, and (header fuzz, seed 304) a DHT segment with more 16-bit
+    codes than there is room for -- where it was the ORACLE that had to change, both times."""
     import glob
     import os
     files = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "damaged", "*.jpg")))

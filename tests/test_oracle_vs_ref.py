@@ -259,6 +259,22 @@ def test_a_dozen_scans(oracle, reference):
     assert _same_coefs(io, ir) and np.array_equal(po, pr)
 
 
+def test_a_table_with_more_codes_than_a_size_has_room_for(oracle, reference):
+    """tests/golden/damaged/oversubscribed_ac_table.jpg (tools/fuzz_headers.py, seed 304, case 734): three more 16-bit
+    codes than the file's AC table 1 has room for (a damaged count in the DHT segment, whose symbols are then read out
+    of the next segment's bytes, decoder.c:163-175).  generate_code_table() counts CODE in 16 bits (huffman.c:91): the
+    last codes wrap to 0, 1, 2, the codes of size 16 are no longer one range, and query_code()'s search in table
+    order (huffman.c:193-225) is what says which bits match.  The oracle had a range test there and lost every 16-bit
+    code of the table; the HIP path, which fills its tables code by code, agreed with the reference all along."""
+    from tests.conftest import golden_path
+    with open(golden_path("damaged/oversubscribed_ac_table.jpg"), "rb") as fh:
+        jpg = fh.read()
+    eo, po, io = oracle.decode(jpg)
+    er, pr, ir = reference.decode(jpg)
+    assert eo == er == 0
+    assert _same_coefs(io, ir) and np.array_equal(po, pr)
+
+
 def test_sample_precisions_beyond_12_bits(oracle, reference):
     """P 13 ... 16 (frame.c:270-275): the oracle against the compiled reference, both directions, on the
     low-contrast images the reference's DC assert leaves it at such precisions (the GPU test uses the same)."""
