@@ -596,6 +596,50 @@ def decode(jpgs, device=0):
         d.close()
 
 
+def decode_mixed(jpgs, device=0):
+    """Codestreams of ANY mix of sizes, sampling and scan layouts -> (list of sample arrays or None, list of RET
+    codes), in the order given.  A decoder batch wants frames of one geometry whose scans agree in number and kind
+    (jpeg_amd.h): the files are grouped by what their headers say (host only), each group is one batch, and a frame
+    that a batch of several refuses as unsupported -- its scans differ from its neighbours' -- is decoded once more in
+    a batch of its own.  The reference takes one file per call (decoder.c:661-685) and has no such notion."""
+    groups, order = {}, []
+    res, sts = [None] * len(jpgs), [RET_FAILURE_FILE_UNSUPPORTED] * len(jpgs)
+    for i, j in enumerate(jpgs):
+        err, fi = parse_info(j)
+        if err:
+            sts[i] = err
+            continue
+        key = (fi.P, fi.X, fi.Y, fi.Nf) + tuple((fi.id[k], fi.H[k], fi.V[k]) for k in range(fi.Nf))
+        if key not in groups:
+            groups[key] = []
+            order.append(key)
+        groups[key].append(i)
+    d = Decoder(device)
+    try:
+        def batch(idx):
+            try:
+                d.prepare([jpgs[i] for i in idx])
+            except JpegError as e:
+                return [None] * len(idx), [e.code] * len(idx)
+            out = d.run()
+            st = d.sync()
+            px = d.to_arrays(out)
+            return [px[k] if st[k] == 0 else None for k in range(len(idx))], st
+        for key in order:
+            idx = groups[key]
+            px, st = batch(idx)
+            for k, i in enumerate(idx):
+                res[i], sts[i] = px[k], st[k]
+            if len(idx) > 1:
+                for k, i in enumerate(idx):
+                    if st[k] == RET_FAILURE_FILE_UNSUPPORTED:
+                        p1, s1 = batch([i])
+                        res[i], sts[i] = p1[0], s1[0]
+        return res, sts
+    finally:
+        d.close()
+
+
 def encode(images, P=8, H=2, V=1, q=75, optimize=1, device=0, restart_interval=0):
     """Convenience: list of same-shaped images -> (list of JPEG bytes, list of RET codes)."""
     a0 = np.asarray(images[0])

@@ -941,3 +941,24 @@ def test_upload_on_a_stream_of_the_callers(hip, oracle):
                 assert np.array_equal(px, want[k0 + k])
     finally:
         d.close()
+
+
+def test_decode_mixed_takes_every_golden_in_one_call(hip, oracle):
+    """binding.decode_mixed(): files of any mix of sizes, sampling and scan layouts in one call -- grouped into batches
+    by their headers, frames whose scans differ from their batch's decoded again on their own."""
+    import json
+    with open(golden_path("manifest.json")) as f:
+        man = json.load(f)
+    names = sorted(set(g["jpg_file"] for k in ("decode", "encode") for g in man[k].values() if "jpg_file" in g))
+    jpgs = []
+    for n in names:
+        with open(golden_path(n), "rb") as fh:
+            jpgs.append(fh.read())
+    jpgs = jpgs + jpgs[::-1]                                   # every file twice, far apart
+    px, st = hip.decode_mixed(jpgs)
+    assert len(px) == len(st) == len(jpgs)
+    for i, j in enumerate(jpgs):
+        oerr, opx, _ = oracle.decode(j)
+        assert (st[i] == 0) == (oerr == 0), (i, hex(st[i] & 0xffffffff), hex(oerr & 0xffffffff))
+        if oerr == 0:
+            assert np.array_equal(px[i], opx), i
