@@ -70,3 +70,35 @@ def deep_image(P, nc, X=160, Y=96, seed=1):
     if nc == 3:
         a = np.stack([a, np.roll(a, 5, 1), np.roll(a, 9, 0)], -1)
     return a
+
+
+def table_per_component(jpg):
+    """A single-scan file rewritten so that the j-th component of its scan reads DC table j and AC table j (copies of
+    the tables it named): with four components all eight table ids of decoder.c:176-182 are in use at once, the most
+    look-up tables a scan can ask the kernels to hold.  The samples it decodes to stay what they were."""
+    segs, i = [], 2
+    while jpg[i + 1] != 0xDA:
+        n = (jpg[i + 2] << 8) | jpg[i + 3]
+        segs.append((jpg[i + 1], jpg[i + 4:i + 2 + n]))
+        i += 2 + n
+    tables = {}
+    for m, body in segs:
+        p = 0
+        while m == 0xC4 and p < len(body):
+            n = sum(body[p + 1:p + 17])
+            tables[body[p] >> 4, body[p] & 15] = body[p + 1:p + 17 + n]
+            p += 17 + n
+    n = (jpg[i + 2] << 8) | jpg[i + 3]
+    sos = bytearray(jpg[i + 4:i + 2 + n])
+    dht = b""
+    for j in range(sos[0]):
+        td, ta = sos[2 + 2 * j] >> 4, sos[2 + 2 * j] & 15
+        dht += bytes([j]) + tables[0, td] + bytes([0x10 | j]) + tables[1, ta]
+        sos[2 + 2 * j] = (j << 4) | j
+    out = jpg[:2]
+    for m, body in segs:
+        if m != 0xC4:
+            out += bytes([0xFF, m]) + (len(body) + 2).to_bytes(2, "big") + body
+    out += b"\xff\xc4" + (len(dht) + 2).to_bytes(2, "big") + dht
+    out += b"\xff\xda" + n.to_bytes(2, "big") + bytes(sos)
+    return out + jpg[i + 2 + n:]

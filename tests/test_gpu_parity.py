@@ -799,6 +799,31 @@ def test_a_dozen_scans(hip, oracle):
         d.close()
 
 
+def test_eight_huffman_tables_in_one_scan(hip, oracle):
+    """Four components with a DC and an AC table each (tests/damaged.py: table_per_component on the CMYK golden):
+    the most look-up tables the Huffman kernels hold in LDS (k_huff_write: 68 KB with its block buffers).  Alone,
+    and in a batch beside the file it was made from (two tables)."""
+    from tests.conftest import golden_path
+    from tests.damaged import table_per_component
+    with open(golden_path("d_pil_cmyk.jpg"), "rb") as fh:
+        jpg = fh.read()
+    eight = table_per_component(jpg)
+    oerr, opx, oinfo = oracle.decode(eight)
+    assert oerr == 0 and oinfo.Nf == 4
+    d = hip.Decoder()
+    try:
+        for batch in ([eight], [jpg, eight, eight, jpg]):
+            d.prepare(batch)
+            out = d.run()
+            assert d.sync() == [0] * len(batch)
+            for k in range(len(batch)):
+                _assert_coefs(d.coefficients(k), oinfo)
+            for px in d.to_arrays(out):
+                assert np.array_equal(px, opx)
+    finally:
+        d.close()
+
+
 def test_components_coded_more_than_once(hip, oracle):
     """decoder.c:593-601 reads whatever scans come; read_block() stores every coefficient of a block it reads
     (coeffs.c:222-229), so a component that is coded again is simply written again.  Files made by splicing scans

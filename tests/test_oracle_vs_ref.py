@@ -275,6 +275,21 @@ def test_a_table_with_more_codes_than_a_size_has_room_for(oracle, reference):
     assert _same_coefs(io, ir) and np.array_equal(po, pr)
 
 
+def test_eight_huffman_tables_in_one_scan(oracle, reference):
+    """The Pillow-written CMYK golden with a DC and an AC table of its own for each of the four components
+    (tests/damaged.py: table_per_component): every table id of decoder.c:176-182 in use in one scan."""
+    from tests.conftest import golden_path
+    from tests.damaged import table_per_component
+    with open(golden_path("d_pil_cmyk.jpg"), "rb") as fh:
+        jpg = fh.read()
+    eight = table_per_component(jpg)
+    eo, po, io = oracle.decode(eight)
+    er, pr, ir = reference.decode(eight)
+    assert eo == er == 0
+    assert _same_coefs(io, ir) and np.array_equal(po, pr)
+    assert np.array_equal(po, oracle.decode(jpg)[1])
+
+
 def test_sample_precisions_beyond_12_bits(oracle, reference):
     """P 13 ... 16 (frame.c:270-275): the oracle against the compiled reference, both directions, on the
     low-contrast images the reference's DC assert leaves it at such precisions (the GPU test uses the same)."""
